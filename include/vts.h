@@ -1,0 +1,161 @@
+/* vts: C ABI of the MI355X (gfx950) LSTM-VAE train-step kernels.
+ *
+ * The reference (letrucnhi160703/vae-time-series) has no FFI: its hot path is the set of torch
+ * call sites cited beside each entry point below (paths relative to vae-models/).  This header
+ * is what a binding for that path binds: plain pointers and sizes, no torch types.
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory owned by the caller (fp32 unless noted), contiguous,
+ *    16-byte aligned where stated; the library never allocates, frees or keeps device memory;
+ *  - all work is enqueued on `stream`; no call synchronises, so calls compose with the caller's
+ *    stream ordering and can be made from any host thread;
+ *  - return 0 on success, otherwise VTS_ERR_* with a message in a thread-local buffer
+ *    (vts_last_error()); no C++ exception crosses the boundary;
+ *  - `dtype_mode`: 0 = fp32 arithmetic on the f32 matrix cores (parity mode).  Other values are
+ *    rejected by this build.
+ *
+ * Layouts
+ *  - sequences are batch-first row-major [B, T, F] exactly as the reference feeds nn.LSTM;
+ *  - "tile16" buffers (gate activations, cell states, sequence gradients) are private to the
+ *    LSTM entry points: a [Bp*T, N] matrix (Bp = B rounded up to 16) with logical row
+ *    (b/16 * T + t) * 16 + b%16, cut into 16x16 blocks stored in MFMA accumulator order.  Callers
+ *    only size them (vts_lstm_*_bytes) and pass them back unchanged from forward to backward;
+ *    vts_tile16_convert() translates to/from row-major for callers that need the contents.
+ */
+#ifndef VTS_H
+#define VTS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vts_stream_t; /* == hipStream_t */
+
+#define VTS_OK 0
+#define VTS_ERR_ARG 1
+#define VTS_ERR_HIP 2
+#define VTS_ERR_UNSUPPORTED 3
+
+/* activation codes of vts_linear_* */
+#define VTS_ACT_NONE 0
+#define VTS_ACT_RELU 1
+#define VTS_ACT_EXP 2          /* torch.exp(head)              gpd-lstm-DE.py:31, mixture-vae-DE.py:67 */
+#define VTS_ACT_CLAMP_MIN 3    /* torch.clamp(head, min=1e-6)  gpd-lstm-DE.py:32, mixture-vae-DE.py:68 */
+#define VTS_ACT_RELU_DROPOUT 4 /* dropout(relu(.)) with the keep mask fed in: gpd-lstm-DE.py:30,46 */
+
+/* latent families of vts_reparam_* / vts_elbo_* */
+#define VTS_GAUSSIAN 0
+#define VTS_GPD 1
+#define VTS_MIXTURE 2
+
+const char* vts_version(void);
+const char* vts_last_error(void);
+
+/* ---- LSTM layer: nn.LSTM(input, H, num_layers, batch_first=True) with zero initial state ----
+ * replaces gaussian-lstm-DE.py:16,28 ; gpd-lstm-DE.py:18,27 ; mixture-vae-DE.py:45,60 (one call
+ * per stacked layer; layer k>0 takes layer k-1's hseq as x).  Gate order i,f,g,o; weights in
+ * torch's shapes: w_ih [4H, Cin], w_hh [4H, H], b_ih/b_hh [4H].  H in {16, 32, 64, 128, 256}. */
+size_t vts_lstm_gates_bytes(int64_t B, int64_t T, int64_t H);      /* tile16 [Bp*T, 4H] */
+size_t vts_lstm_cells_bytes(int64_t B, int64_t T, int64_t H);      /* tile16 [Bp*T, H]  */
+size_t vts_lstm_seqgrad_bytes(int64_t B, int64_t T, int64_t F);    /* tile16 [Bp*T, F]  */
+size_t vts_lstm_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H);
+
+/* forward: writes gates (activated i,f,g,o), cells (c_t), hseq [B,T,H]; h_last / c_last [B,H]
+ * (the layer's slice of h_n / c_n) are optional. */
+int vts_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                       const float* b_hh, float* gates, float* cells, float* hseq, float* h_last,
+                       float* c_last,
+                       void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin,
+                       int64_t H, int dtype_mode, vts_stream_t stream);
+
+/* backward: consumes gates (overwritten with the gate pre-activation gradients).
+ * Upstream gradients, each optional (NULL = zero): dh_seq_t16 tile16 [Bp*T, H] (what the layer
+ * above wrote into its dx_t16), dh_last [B,H] and dc_last [B,H] row-major.
+ * Outputs: dx_t16 tile16 [Bp*T, Cin] (NULL for the first layer: the input needs no gradient),
+ * dw_ih, dw_hh, db_ih, db_hh in torch's shapes; accumulate != 0 adds into them. */
+int vts_lstm_layer_bwd(const float* x, const float* hseq, const float* w_ih, const float* w_hh,
+                       float* gates, const float* cells, const float* dh_seq_t16,
+                       const float* dh_last, const float* dc_last, float* dx_t16, float* dw_ih,
+                       float* dw_hh, float* db_ih, float* db_hh, int accumulate, void* workspace,
+                       size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H,
+                       int dtype_mode, vts_stream_t stream);
+
+/* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
+int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,
+                       vts_stream_t stream);
+
+/* ---- Linear (+ fused activation): nn.Linear / F.relu / nn.Dropout / exp / clamp call sites ----
+ * gaussian-lstm-DE.py:30-31,43-45 ; gpd-lstm-DE.py:29-33,45-47 ; mixture-vae-DE.py:62-68,81-83.
+ * y[M,N] = act(x[M,K] . w[N,K]^T + bias).  x may be a strided view (row stride ldx floats), which
+ * is how h_n[-1] is read straight out of hseq.  keep: [M,N] 0/1 mask (VTS_ACT_RELU_DROPOUT,
+ * NULL = eval mode), scaled by keep_scale = 1/(1-p).  aux: [M,N] written by VTS_ACT_CLAMP_MIN
+ * (1 where the gradient passes). */
+int vts_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                   int64_t M, int64_t N, int64_t K, int act, const float* keep, float keep_scale,
+                   float* aux, int dtype_mode, vts_stream_t stream);
+size_t vts_linear_bwd_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* dy, y, aux: [M,N].  dx (row stride lddx, NULL = not needed; dx_accumulate adds), dw [N,K],
+ * db [N] (param_accumulate adds). */
+int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, float keep_scale,
+                   const float* x, int64_t ldx, const float* w, float* dx, int64_t lddx,
+                   int dx_accumulate, float* dw, float* db, int param_accumulate, void* workspace,
+                   size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
+                   vts_stream_t stream);
+
+/* ---- LayerNorm over the last dim (eps 1e-5): gpd-lstm-DE.py:19,28 ; mixture-vae-DE.py:46,61 ---- */
+int vts_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                      float* mean, float* rstd, int64_t M, int64_t H, float eps, vts_stream_t stream);
+size_t vts_layernorm_bwd_workspace_bytes(int64_t M, int64_t H);
+int vts_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, float* dx, int64_t lddx, float* dgamma,
+                      float* dbeta, int param_accumulate, void* workspace, size_t workspace_bytes,
+                      int64_t M, int64_t H, vts_stream_t stream);
+
+/* ---- Reparameterisation, noise fed in ----
+ * VTS_GAUSSIAN: z = mean + eps*exp(0.5*logvar)          gaussian-lstm-DE.py:55-58, mixture-vae-DE.py:10-13
+ * VTS_GPD     : z = scale/shape*((1-u)**(-shape)-1)     gpd-lstm-DE.py:10-12,     mixture-vae-DE.py:16-18
+ * VTS_MIXTURE : row i takes the Gaussian sample iff choice[i] < softmax(pi)[0], else the GPD one
+ *               (the per-row Python loop at mixture-vae-DE.py:94-107 as one kernel).
+ * All latent tensors [B,L]; choice [B]; pi [2].  Unused inputs may be NULL. */
+int vts_reparam_fwd(int family, const float* mean, const float* logvar, const float* scale,
+                    const float* shape, const float* eps, const float* u, const float* choice,
+                    const float* pi, float* z, int64_t B, int64_t L, vts_stream_t stream);
+int vts_reparam_bwd(int family, const float* dz, const float* logvar, const float* scale,
+                    const float* shape, const float* eps, const float* u, const float* choice,
+                    const float* pi, float* dmean, float* dlogvar, float* dscale, float* dshape,
+                    int64_t B, int64_t L, vts_stream_t stream);
+
+/* ---- ELBO losses ----
+ * VTS_GAUSSIAN: mse(recon,y) + beta*mean_B(-0.5*sum_L(1+lv-mu^2-e^lv))        gaussian-lstm-DE.py:66-70
+ * VTS_GPD     : mse(recon,y) + beta*mean(log scale + log(1+shape*thr/scale))   gpd-lstm-DE.py:67-71
+ * VTS_MIXTURE : mse + pi0*(mse over |y|<=thr + beta*KLg) + pi1*(mse + beta*KLp) mixture-vae-DE.py:115-130
+ *               (NaN when no |y| <= thr, as the reference)
+ * fwd writes state[16]: state[0] = loss, the rest are coefficients for bwd.  bwd scales every
+ * gradient by *grad_out (device scalar, NULL = 1).  recon,y [B,fs]; latents [B,L]; pi, dpi [2]. */
+size_t vts_elbo_workspace_bytes(int64_t B, int64_t fs, int64_t L);
+int vts_elbo_fwd(int family, const float* recon, const float* y, const float* mean,
+                 const float* logvar, const float* scale, const float* shape, const float* pi,
+                 float threshold, float beta, float* state, void* workspace, size_t workspace_bytes,
+                 int64_t B, int64_t fs, int64_t L, vts_stream_t stream);
+int vts_elbo_bwd(int family, const float* recon, const float* y, const float* mean,
+                 const float* logvar, const float* scale, const float* shape, const float* state,
+                 const float* grad_out, float threshold, float* drecon, float* dmean, float* dlogvar,
+                 float* dscale, float* dshape, float* dpi, int64_t B, int64_t fs, int64_t L,
+                 vts_stream_t stream);
+
+/* ---- Adam (torch.optim.Adam defaults, no weight decay) over one flat buffer ----
+ * gaussian-lstm-DE.py:142,154 ; gpd-lstm-DE.py:88,104 ; mixture-vae-DE.py:147,163.
+ * step is 1-based; grad_scale multiplies g first (1/world_size after a summed all-reduce). */
+int vts_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                  vts_stream_t stream);
+
+/* out[i] = in[i] * (*scalar) */
+int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTS_H */

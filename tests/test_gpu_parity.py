@@ -1,0 +1,352 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and against the
+fixtures recorded from the reference.  Tolerance is the north star's: rel 1e-4 on the loss and
+on every parameter gradient (L2-relative per tensor), except where stated."""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def l2_rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def kind_of(name):
+    return name.split("_")[0]
+
+
+def make_model(kind, dims, sd, threshold, beta, dev):
+    import vts
+    B, T, C, H, Ld, fs = dims
+    m = vts.build_model(kind, C, H, Ld, fs, beta=beta, threshold=threshold).to(dev)
+    m.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+    return m
+
+
+def run_vts(kind, g, dev, train=True):
+    dims = [int(v) for v in g["meta"]["dims"]]
+    m = make_model(kind, dims, g["sd"], g["meta"]["threshold"], g["meta"]["beta"], dev)
+    m.train(train)
+    noise = {k: v.to(dev) for k, v in g["noise"].items()}
+    outs = m(g["x"].to(dev), noise)
+    loss = m.loss_function(outs[0], g["y"].to(dev), *outs[1:])
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    return loss, outs, grads
+
+
+WELL_CONDITIONED = [
+    "gaussian_tiny", "gaussian_native", "gaussian_wide", "mixture_tiny", "mixture_native",
+    "mixture_wide", "mixture_tiny_eval", "gpd_tiny_clamped", "mixture_native_clamped",
+    "gpd_native_wellcond", "gpd_wide_wellcond", "mixture_wide_wellcond_mixedmask",
+    "mixture_native_mixedmask",
+]
+OUT_NAMES = {"gaussian": ["recon", "mean", "logvar"], "gpd": ["recon", "scale", "shape"],
+             "mixture": ["recon", "mean", "logvar", "scale", "shape"]}
+
+
+@pytest.mark.parametrize("name", WELL_CONDITIONED)
+def test_golden_loss_and_gradients(golden, name):
+    """Reference fixtures: loss within 1e-4 relative, every gradient within 1e-4 L2-relative."""
+    g = golden(name)
+    kind = kind_of(name)
+    loss, outs, grads = run_vts(kind, g, _dev(), train=bool(g["meta"]["train"]))
+    ref_loss = float(g["loss"])
+    assert abs(loss.item() - ref_loss) <= TOL * abs(ref_loss), (loss.item(), ref_loss)
+    for nm, o in zip(OUT_NAMES[kind], outs):
+        assert l2_rel(o, g["out"][nm]) < TOL, nm
+    for k, ref in g["grad"].items():
+        if ref.abs().max() == 0:
+            assert grads[k].abs().max().item() == 0, k
+        else:
+            assert l2_rel(grads[k], ref) < TOL, (k, l2_rel(grads[k], ref))
+
+
+@pytest.mark.parametrize("name", ["gpd_tiny", "gpd_native", "gpd_wide", "gpd_tiny_eval"])
+def test_golden_default_init_gpd(golden, name):
+    """Default-init GPD: about half the shapes sit at / just above the 1e-6 clamp where the
+    sampler's fp32 cancellation makes the reference's own gradients move by up to ~1e-2 under a
+    last-bit change of the LSTM output (tests/test_oracle_goldens.py records that floor).
+    Forward quantities that do not pass through the sampler keep the 1e-4 bound; the loss and
+    gradients are held to 10x the recorded floor."""
+    g = golden(name)
+    loss, outs, grads = run_vts("gpd", g, _dev(), train=bool(g["meta"]["train"]))
+    assert l2_rel(outs[1], g["out"]["scale"]) < TOL
+    assert l2_rel(outs[2], g["out"]["shape"]) < TOL
+    _, _, floor_grads = R.loss_and_grads("gpd", g["sd"], g["x"], g["y"], g["noise"], stock=False)
+    floor = max(l2_rel(floor_grads[k], ref) for k, ref in g["grad"].items())
+    bound = max(10 * floor, 1e-3)
+    assert abs(loss.item() - float(g["loss"])) <= bound * abs(float(g["loss"]))
+    for k, ref in g["grad"].items():
+        assert l2_rel(grads[k], ref) < bound, (k, l2_rel(grads[k], ref), bound)
+
+
+def test_empty_normal_mask_gives_nan(golden):
+    g = golden("mixture_tiny_emptymask")
+    loss, _, _ = run_vts("mixture", g, _dev())
+    assert math.isnan(loss.item())
+
+
+def test_clamped_shape_gets_zero_gradient(golden):
+    g = golden("gpd_tiny_clamped")
+    _, outs, grads = run_vts("gpd", g, _dev())
+    assert torch.all(outs[2] == 1e-6)
+    assert torch.all(grads["encoder.shape_layer_extreme.weight"] == 0)
+    assert torch.all(grads["encoder.shape_layer_extreme.bias"] == 0)
+
+
+# ------------------------------------------------------------------------------ LSTM alone
+@pytest.mark.parametrize("B,T,C,H,layers", [
+    (1, 1, 1, 16, 1),        # smallest possible
+    (5, 3, 2, 32, 2),        # ragged batch (not a multiple of 16), odd channel count
+    (16, 16, 1, 64, 3),      # reference-native
+    (33, 7, 37, 64, 1),      # ragged batch across three 16-row tiles, C % 2 == 1
+    (40, 12, 370, 128, 2),   # LD2011 channel count (C % 4 == 2)
+    (48, 9, 20, 256, 3),     # headline hidden size
+])
+def test_lstm_matches_oracle(B, T, C, H, layers):
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    lstm = vts.LSTM(C, H, num_layers=layers).to(dev)
+    sd = {"encoder.lstm." + k: v.detach().cpu() for k, v in lstm.state_dict().items()}
+    x = torch.randn(B, T, C, generator=g)
+    w_out = torch.randn(B, T, H, generator=g)
+    w_h = torch.randn(layers, B, H, generator=g)
+    w_c = torch.randn(layers, B, H, generator=g)
+
+    # oracle (torch's fused CPU LSTM) with full outputs
+    ref = torch.nn.LSTM(C, H, num_layers=layers, batch_first=True)
+    ref.load_state_dict({k[len("encoder.lstm."):]: v for k, v in sd.items()})
+    out_r, (hn_r, cn_r) = ref(x)
+    (out_r * w_out).sum().add((hn_r * w_h).sum()).add((cn_r * w_c).sum()).backward()
+
+    out, (hn, cn) = lstm(x.to(dev))
+    ((out * w_out.to(dev)).sum() + (hn * w_h.to(dev)).sum() + (cn * w_c.to(dev)).sum()).backward()
+    assert l2_rel(out, out_r) < TOL
+    assert l2_rel(hn, hn_r) < TOL
+    assert l2_rel(cn, cn_r) < TOL
+    for k, p in lstm.named_parameters():
+        assert l2_rel(p.grad, getattr(ref, k).grad) < TOL, k
+
+
+def test_lstm_input_gradient():
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, T, C, H = 19, 6, 32, 64
+    lstm = vts.LSTM(C, H, num_layers=2).to(dev)
+    ref = torch.nn.LSTM(C, H, num_layers=2, batch_first=True)
+    ref.load_state_dict({k: v.cpu() for k, v in lstm.state_dict().items()})
+    x = torch.randn(B, T, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    xd = x.to(dev).requires_grad_(True)
+    ref(xr)[1][0][-1].pow(2).sum().backward()
+    lstm(xd)[1][0][-1].pow(2).sum().backward()
+    assert l2_rel(xd.grad, xr.grad) < TOL
+
+
+def test_lstm_rejects_unsupported():
+    import vts
+    with pytest.raises(NotImplementedError):
+        vts.LSTM(4, 48)
+    with pytest.raises(NotImplementedError):
+        vts.LSTM(4, 64, bidirectional=True)
+    lstm = vts.LSTM(4, 16)
+    with pytest.raises(RuntimeError):
+        lstm(torch.zeros(2, 3, 4))  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------- individual ops
+@pytest.mark.parametrize("M,K,N,act", [
+    (16, 64, 32, 0), (37, 256, 128, 1), (130, 128, 64, 4), (16, 64, 32, 2), (257, 64, 32, 3),
+    (64, 500, 1, 0), (4096, 32, 500, 1), (200, 128, 500, 4),
+])
+def test_linear_ops(M, K, N, act):
+    import vts
+    from vts import _lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + K + N + act)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    keep = (torch.rand(M, N, generator=g) >= 0.3).float()
+    dy = torch.randn(M, N, generator=g)
+
+    def ref_fn(x, w, b):
+        pre = torch.nn.functional.linear(x, w, b)
+        if act == 1:
+            return torch.relu(pre)
+        if act == 2:
+            return torch.exp(pre)
+        if act == 3:
+            return torch.clamp(pre, min=1e-6)
+        if act == 4:
+            return torch.relu(pre) * keep / 0.7
+        return pre
+
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yr = ref_fn(xr, wr, br)
+    yr.backward(dy)
+    xd, wd, bd = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+    yd = vts.linear(xd, wd, bd, act, keep.to(dev) if act == 4 else None)
+    yd.backward(dy.to(dev))
+    assert l2_rel(yd, yr) < 1e-5
+    assert l2_rel(xd.grad, xr.grad) < 1e-5
+    assert l2_rel(wd.grad, wr.grad) < 1e-5
+    assert l2_rel(bd.grad, br.grad) < 1e-5
+
+
+def test_linear_strided_input():
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    seq = torch.randn(20, 5, 64, generator=g)
+    w = torch.randn(8, 64, generator=g)
+    y = vts.linear(seq.to(dev)[:, -1, :], w.to(dev), None)
+    assert l2_rel(y, seq[:, -1, :] @ w.t()) < 1e-5
+
+
+@pytest.mark.parametrize("M,H", [(16, 64), (37, 256), (1000, 16)])
+def test_layer_norm(M, H):
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + H)
+    x = torch.randn(M, H, generator=g) * 2 + 0.5
+    gam = torch.randn(H, generator=g)
+    bet = torch.randn(H, generator=g)
+    dy = torch.randn(M, H, generator=g)
+    xr, gr, br = [t.clone().requires_grad_(True) for t in (x, gam, bet)]
+    torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-5).backward(dy)
+    xd, gd, bd = [t.to(dev).requires_grad_(True) for t in (x, gam, bet)]
+    yd = vts.layer_norm(xd, gd, bd)
+    yd.backward(dy.to(dev))
+    assert l2_rel(yd, torch.nn.functional.layer_norm(x, (H,), gam, bet, 1e-5)) < 1e-5
+    assert l2_rel(xd.grad, xr.grad) < 1e-5
+    assert l2_rel(gd.grad, gr.grad) < 1e-5
+    assert l2_rel(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,Ld", [(16, 32), (4096, 32), (7, 8)])
+def test_reparam_and_elbo_ops(B, Ld):
+    """Each fused kernel against the oracle's formula on identical inputs (1e-5: same fp32
+    expressions, only libm differences)."""
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + Ld)
+    mean = torch.randn(B, Ld, generator=g)
+    logvar = torch.randn(B, Ld, generator=g) * 0.5
+    scale = torch.exp(torch.randn(B, Ld, generator=g) * 0.3)
+    shape_raw = torch.randn(B, Ld, generator=g) * 0.2
+    shape = torch.clamp(shape_raw, min=1e-6)
+    eps = torch.randn(B, Ld, generator=g)
+    u = torch.rand(B, Ld, generator=g)
+    choice = torch.rand(B, generator=g)
+    pi = torch.tensor([0.3, 0.1])
+    recon = torch.randn(B, 1, generator=g)
+    y = torch.randn(B, 1, generator=g)
+    dz = torch.randn(B, Ld, generator=g)
+
+    leaves = [t.clone().requires_grad_(True) for t in (mean, logvar, scale, shape, pi, recon)]
+    m_, lv_, sc_, sh_, pi_, rc_ = leaves
+    zr = R.mixture_select(R.reparam_gaussian(m_, lv_, eps), R.reparam_gpd(sc_, sh_, u), pi_, choice)
+    lr = R.loss_mixture(rc_, y, m_, lv_, sc_, sh_, pi_, threshold=0.5, beta=0.01)
+    (zr * dz).sum().add(lr * 1.7).backward()
+
+    d = [t.to(dev).requires_grad_(True) for t in (mean, logvar, scale, shape, pi, recon)]
+    md, lvd, scd, shd, pid, rcd = d
+    zd = vts.reparameterize_mixture(md, lvd, scd, shd, pid, choice.to(dev), eps.to(dev), u.to(dev))
+    ld = vts.mixture_elbo(rcd, y.to(dev), md, lvd, scd, shd, pid, threshold=0.5, beta=0.01)
+    ((zd * dz.to(dev)).sum() + ld * 1.7).backward()
+    # unclamped small shapes amplify libm last-bit differences in z by ~1e-7/shape
+    assert torch.allclose(zd.cpu(), zr.detach(), rtol=1e-4, atol=1e-4)
+    assert abs(ld.item() - lr.item()) < 1e-5 * abs(lr.item())
+    for a, b, nm in zip(d, leaves, ["mean", "logvar", "scale", "shape", "pi", "recon"]):
+        tol = 2e-3 if nm == "shape" else 1e-5   # d/dshape is itself a cancelling difference
+        assert l2_rel(a.grad, b.grad) < tol, nm
+
+    # single-family entry points
+    zg = vts.reparameterize_gaussian(mean.to(dev), logvar.to(dev), eps.to(dev))
+    assert l2_rel(zg, R.reparam_gaussian(mean, logvar, eps)) < 1e-6
+    sh_ok = torch.clamp(shape_raw.abs() + 0.05, min=1e-6)
+    zp = vts.reparameterize_gpd(scale.to(dev), sh_ok.to(dev), None, u.to(dev))
+    assert l2_rel(zp, R.reparam_gpd(scale, sh_ok, u)) < 1e-5
+    lg = vts.gaussian_elbo(recon.to(dev), y.to(dev), mean.to(dev), logvar.to(dev), 0.001)
+    assert abs(lg.item() - R.loss_gaussian(recon, y, mean, logvar).item()) < 1e-5 * abs(lg.item())
+    lp = vts.gpd_elbo(recon.to(dev), y.to(dev), scale.to(dev), shape.to(dev), 95.0, 0.001)
+    assert abs(lp.item() - R.loss_gpd(recon, y, scale, shape).item()) < 1e-5 * abs(lp.item())
+
+
+def test_gpd_sampler_is_bit_exact_at_the_clamp():
+    """shape == 1e-6: z = scale/1e-6 * ((1-u)**(-1e-6) - 1) is quantised in steps of
+    ~0.119*scale; only a correctly rounded pow reproduces the reference's values."""
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    scale = torch.exp(torch.randn(512, 32, generator=g) * 0.3)
+    shape = torch.full((512, 32), 1e-6)
+    u = torch.rand(512, 32, generator=g)
+    zr = R.reparam_gpd(scale, shape, u)
+    zd = vts.reparameterize_gpd(scale.to(dev), shape.to(dev), None, u.to(dev)).cpu()
+    assert torch.equal(zd, zr)
+
+
+# --------------------------------------------------------------------------- Adam, a10
+@pytest.mark.parametrize("kind", ["gaussian", "mixture", "gpd"])
+def test_adam_trajectory(golden, kind):
+    import vts
+    dev = _dev()
+    g = golden(f"adam_{kind}_native")
+    dims = [int(v) for v in g["meta"]["dims"]]
+    m = make_model(kind, dims, g["sd0"], g["meta"]["threshold"], g["meta"]["beta"], dev)
+    m.train()
+    flat = vts.FlatParameters(m)
+    opt = vts.Adam(flat, lr=g["meta"]["lr"])
+    steps = g["meta"]["steps"]
+    for s in range(steps):
+        st = g[f"step{s}"]
+        noise = {k: v.to(dev) for k, v in st["noise"].items()}
+        loss = vts.train_step(m, opt, st["x"].to(dev), st["y"].to(dev), noise)
+        ref = float(g["losses"][s])
+        ltol = 2e-3 if kind == "gpd" else TOL
+        assert abs(loss.item() - ref) <= ltol * max(1.0, abs(ref)), (s, loss.item(), ref)
+    for k, ref in g["sdK"].items():
+        got = m.state_dict()[k].cpu()
+        if kind == "gpd":   # see tests/test_oracle_goldens.py::test_adam_trajectory
+            assert (got - ref).abs().max().item() <= 2 * g["meta"]["lr"] * steps, k
+        else:
+            assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-6, k
+
+
+def test_large_batch_against_oracle_slice():
+    """Headline channel/hidden sizes on a batch the CPU oracle finishes in seconds."""
+    import vts
+    dev = _dev()
+    B, T, C, H, Ld = 64, 24, 370, 256, 32
+    for kind in ("gaussian", "mixture"):
+        sd = R.init_state(kind, C, H, Ld, 1, seed=1)
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(B, T, C, generator=g)
+        y = torch.randn(B, 1, generator=g)
+        noise = R.draw_noise(kind, B, Ld, seed=3)
+        loss_r, _, grads_r = R.loss_and_grads(kind, sd, x, y, noise)
+        m = make_model(kind, (B, T, C, H, Ld, 1), sd, 95.0, 0.001, dev)
+        m.train()
+        outs = m(x.to(dev), {k: v.to(dev) for k, v in noise.items()})
+        loss = m.loss_function(outs[0], y.to(dev), *outs[1:])
+        loss.backward()
+        assert abs(loss.item() - loss_r.item()) <= TOL * abs(loss_r.item())
+        for k, p in m.named_parameters():
+            assert l2_rel(p.grad, grads_r[k]) < TOL, (kind, k, l2_rel(p.grad, grads_r[k]))

@@ -1,0 +1,495 @@
+// HBM-bound pieces of the train step: reparameterisation (Gaussian / GPD / mixture row select),
+// the three ELBO losses with their gradients, LayerNorm, activation gradients, column sums and
+// the Adam update.  All fp32, 16-byte accesses where the shapes allow, wave64 shuffle reductions.
+#include "vts_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// Block-wide sum of NV values per thread; result valid in thread 0.  blockDim.x == 256.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* smem /* [4*NV] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = wave_sum(v[i]);
+    if (lane == 0) smem[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = smem[i] + smem[NV + i] + smem[2 * NV + i] + smem[3 * NV + i];
+  }
+}
+
+// ------------------------------------------------------------------------------ reparameterise
+// softmax(pi)[0] the way torch computes a 2-element fp32 softmax (subtract max, exp, normalise).
+__device__ __forceinline__ float softmax0(const float* pi) {
+  const float a = pi[0], b = pi[1];
+  const float m = fmaxf(a, b);
+  const float ea = expf(a - m), eb = expf(b - m);
+  return ea / (ea + eb);
+}
+
+// GPD inverse-CDF sample, same operation order as the reference expression
+// scale / shape * ((1 - u) ** (-shape) - 1).  The power is evaluated in fp64 and rounded once:
+// near the shape clamp (1e-6) the result sits a few ulps above 1 and the subtraction that
+// follows amplifies any last-bit difference by ~1e6, so the power must be correctly rounded
+// (torch's CPU fp32 pow is, in that regime).
+__device__ __forceinline__ float gpd_pow(float base, float expo) {
+  return (float)pow((double)base, (double)expo);
+}
+
+// mode 0: z = mean + eps*exp(0.5*logvar)
+// mode 1: z = GPD sample
+// mode 2: z = row-select(choice < softmax(pi)[0] ? gaussian : gpd)
+__global__ void reparam_fwd_kernel(int mode, const float* __restrict__ mean, const float* __restrict__ logvar,
+                                   const float* __restrict__ scale, const float* __restrict__ shape,
+                                   const float* __restrict__ eps, const float* __restrict__ u,
+                                   const float* __restrict__ choice, const float* __restrict__ pi,
+                                   float* __restrict__ z, long n, int L) {
+  float p0 = 0.f;
+  if (mode == 2) p0 = softmax0(pi);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    bool gauss = (mode == 0);
+    if (mode == 2) gauss = choice[i / L] < p0;
+    float out;
+    if (gauss) {
+      out = mean[i] + eps[i] * expf(0.5f * logvar[i]);
+    } else {
+      const float sc = scale[i], sh = shape[i];
+      const float p = gpd_pow(1.0f - u[i], -sh);
+      out = (sc / sh) * (p - 1.0f);
+    }
+    z[i] = out;
+  }
+}
+
+// Gradients w.r.t. mean, logvar, scale, shape given dz (unselected family gets 0 in mode 2).
+// GPD branch mirrors autograd's decomposition of scale/shape*((1-u)**(-shape)-1):
+//   a = scale/shape, q = p-1, z = a*q;  da = dz*q, dq = dz*a
+//   dscale = da/shape,  dshape = -da*(a/shape) - dq*p*log(1-u)
+__global__ void reparam_bwd_kernel(int mode, const float* __restrict__ dz, const float* __restrict__ logvar,
+                                   const float* __restrict__ scale, const float* __restrict__ shape,
+                                   const float* __restrict__ eps, const float* __restrict__ u,
+                                   const float* __restrict__ choice, const float* __restrict__ pi,
+                                   float* __restrict__ dmean, float* __restrict__ dlogvar,
+                                   float* __restrict__ dscale, float* __restrict__ dshape, long n, int L) {
+  float p0 = 0.f;
+  if (mode == 2) p0 = softmax0(pi);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    bool gauss = (mode == 0);
+    if (mode == 2) gauss = choice[i / L] < p0;
+    const float d = dz[i];
+    if (mode != 1) {
+      float dm = 0.f, dl = 0.f;
+      if (gauss) {
+        dm = d;
+        dl = d * eps[i] * expf(0.5f * logvar[i]) * 0.5f;
+      }
+      dmean[i] = dm;
+      dlogvar[i] = dl;
+    }
+    if (mode != 0) {
+      float dsc = 0.f, dsh = 0.f;
+      if (!gauss) {
+        const float sc = scale[i], sh = shape[i];
+        const float base = 1.0f - u[i];
+        const float p = gpd_pow(base, -sh);
+        const float a = sc / sh;
+        const float q = p - 1.0f;
+        const float da = d * q, dq = d * a;
+        dsc = da / sh;
+        const float de = dq * (p * logf(base));   // d/d(exponent); exponent = -shape
+        dsh = -da * (a / sh) - de;
+      }
+      dscale[i] = dsc;
+      dshape[i] = dsh;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- ELBO
+// kind 0 gaussian, 1 gpd, 2 mixture.  Partial sums per block, 5 slots:
+//   0: sum (recon-y)^2          1: same over |y| <= thr      2: count |y| <= thr
+//   3: sum 1 + lv - mu^2 - e^lv 4: sum log(scale) + log(1 + shape*thr/scale)
+__global__ __launch_bounds__(256) void elbo_partials_kernel(
+    int kind, const float* __restrict__ recon, const float* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ logvar, const float* __restrict__ scale, const float* __restrict__ shape,
+    float thr, long nrec, long nlat, float* __restrict__ part) {
+  __shared__ float smem[20];
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = start; i < nrec; i += stride) {
+    const float yv = y[i];
+    const float d = recon[i] - yv;
+    const float d2 = d * d;
+    s[0] += d2;
+    if (kind == 2 && fabsf(yv) <= thr) { s[1] += d2; s[2] += 1.f; }
+  }
+  for (long i = start; i < nlat; i += stride) {
+    if (kind != 1) {
+      const float lv = logvar[i], mu = mean[i];
+      s[3] += 1.f + lv - mu * mu - expf(lv);
+    }
+    if (kind != 0) {
+      const float sc = scale[i], sh = shape[i];
+      s[4] += logf(sc) + logf(1.f + sh * thr / sc);
+    }
+  }
+  block_sum<5>(s, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) part[(long)blockIdx.x * 5 + i] = s[i];
+  }
+}
+
+// out[0] = loss; out[1..7] = coefficients used by elbo_grads_kernel; out[8], out[9] = d loss / d pi_params
+//   1: c_all   d loss / d recon = c_all * (recon-y) (+ c_norm * (recon-y) on normal rows)
+//   2: c_norm  3: c_klg (multiplies d/dx of sum(1+lv-mu^2-e^lv))  4: c_klp
+__global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, int nparts,
+                                     const float* __restrict__ pi, float beta, long B, long nrec, long nlat,
+                                     float* __restrict__ out) {
+  __shared__ float smem[20];
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < nparts; p += blockDim.x)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s[i] += part[(long)p * 5 + i];
+  block_sum<5>(s, smem);
+  if (threadIdx.x != 0) return;
+  const float R = s[0] / (float)nrec;
+  const float klg = -0.5f * s[3] / (float)B;
+  const float klp = s[4] / (float)nlat;
+  float loss, c_all, c_norm = 0.f, c_klg = 0.f, c_klp = 0.f, dpi0 = 0.f, dpi1 = 0.f;
+  if (kind == 0) {
+    loss = R + beta * klg;
+    c_all = 2.f / (float)nrec;
+    c_klg = beta * -0.5f / (float)B;
+  } else if (kind == 1) {
+    loss = R + beta * klp;
+    c_all = 2.f / (float)nrec;
+    c_klp = beta / (float)nlat;
+  } else {
+    const float a = pi[0], b = pi[1];
+    const float m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    const float p0 = ea / (ea + eb), p1 = eb / (ea + eb);
+    const float Rg = s[1] / s[2];  // 0/0 = NaN when no row is "normal", as mse_loss of an empty tensor
+    const float Ag = Rg + beta * klg;
+    const float Ap = R + beta * klp;
+    loss = R + p0 * Ag + p1 * Ap;
+    c_all = (1.f + p1) * 2.f / (float)nrec;
+    c_norm = p0 * 2.f / s[2];
+    c_klg = p0 * beta * -0.5f / (float)B;
+    c_klp = p1 * beta / (float)nlat;
+    dpi0 = p0 * p1 * (Ag - Ap);
+    dpi1 = -dpi0;
+  }
+  out[0] = loss; out[1] = c_all; out[2] = c_norm; out[3] = c_klg; out[4] = c_klp;
+  out[5] = 0.f; out[6] = 0.f; out[7] = 0.f; out[8] = dpi0; out[9] = dpi1;
+}
+
+// Elementwise ELBO gradients scaled by the upstream scalar *gout (or 1 when gout == nullptr).
+__global__ void elbo_grads_kernel(int kind, const float* __restrict__ recon, const float* __restrict__ y,
+                                  const float* __restrict__ mean, const float* __restrict__ logvar,
+                                  const float* __restrict__ scale, const float* __restrict__ shape,
+                                  const float* __restrict__ coef, const float* __restrict__ gout, float thr,
+                                  long nrec, long nlat, float* __restrict__ drecon, float* __restrict__ dmean,
+                                  float* __restrict__ dlogvar, float* __restrict__ dscale,
+                                  float* __restrict__ dshape, float* __restrict__ dpi) {
+  const float go = gout ? gout[0] : 1.f;
+  const float c_all = coef[1] * go, c_norm = coef[2] * go, c_klg = coef[3] * go, c_klp = coef[4] * go;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (start == 0 && kind == 2 && dpi) { dpi[0] = coef[8] * go; dpi[1] = coef[9] * go; }
+  for (long i = start; i < nrec; i += stride) {
+    const float yv = y[i];
+    const float d = recon[i] - yv;
+    float gr = c_all * d;
+    if (kind == 2 && fabsf(yv) <= thr) gr += c_norm * d;
+    drecon[i] = gr;
+  }
+  for (long i = start; i < nlat; i += stride) {
+    if (kind != 1) {
+      const float lv = logvar[i], mu = mean[i];
+      dmean[i] = c_klg * (-2.f * mu);
+      dlogvar[i] = c_klg * (1.f - expf(lv));
+    }
+    if (kind != 0) {
+      const float sc = scale[i], sh = shape[i];
+      const float w = 1.f + sh * thr / sc;
+      dscale[i] = c_klp * (1.f / sc - (sh * thr / (sc * sc)) / w);
+      dshape[i] = c_klp * ((thr / sc) / w);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------- LayerNorm
+// One wave per row; H <= 1024.  Saves mean and rstd per row.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int M, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long)row * ldx;
+  float s = 0.f;
+  for (int j = lane; j < H; j += 64) s += xr[j];
+  const float mu = wave_sum(s) / (float)H;
+  float v = 0.f;
+  for (int j = lane; j < H; j += 64) { const float d = xr[j] - mu; v += d * d; }
+  const float rs = 1.0f / sqrtf(wave_sum(v) / (float)H + eps);
+  for (int j = lane; j < H; j += 64) y[(long)row * H + j] = (xr[j] - mu) * rs * gamma[j] + beta[j];
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx (row stride lddx) = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma.
+// dgamma / dbeta partials per block: part[blk][2][H].
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy,
+                                                            const float* __restrict__ x, long ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            long lddx, float* __restrict__ part, int M, int H,
+                                                            int rows_per_block) {
+  extern __shared__ float sm[];  // [2][H] accumulators
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < 2 * H; j += blockDim.x) sm[j] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (long)row * ldx;
+    const float* dyr = dy + (long)row * H;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < H; j += 64) {
+      const float xh = (xr[j] - mu) * rs;
+      const float dxh = dyr[j] * gamma[j];
+      s1 += dxh;
+      s2 += dxh * xh;
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    for (int j = lane; j < H; j += 64) {
+      const float xh = (xr[j] - mu) * rs;
+      const float dxh = dyr[j] * gamma[j];
+      dx[(long)row * lddx + j] = rs * (dxh - s1 - xh * s2);
+      atomicAdd(&sm[j], dyr[j] * xh);      // LDS atomics, 4 waves share the accumulators
+      atomicAdd(&sm[H + j], dyr[j]);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * H; j += blockDim.x) part[(long)blockIdx.x * 2 * H + j] = sm[j];
+}
+
+// -------------------------------------------------------------------------- activation gradient
+// kind 1 relu: dy*(y>0) | 2 exp: dy*y | 3 clamp: dy*aux | 4 relu+dropout: dy*scale*(y!=0)
+__global__ void act_bwd_kernel(int kind, const float* __restrict__ dy, const float* __restrict__ y,
+                               const float* __restrict__ aux, float scale, float* __restrict__ dpre, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = dy[i];
+    float o;
+    if (kind == 1) o = (y[i] > 0.f) ? d : 0.f;
+    else if (kind == 2) o = d * y[i];
+    else if (kind == 3) o = d * aux[i];
+    else o = (y[i] != 0.f) ? d * scale : 0.f;
+    dpre[i] = o;
+  }
+}
+
+// Column sums of a row-major [M][N] matrix over a chunk of rows: part[chunk][N].
+__global__ void colsum_rows_kernel(const float* __restrict__ a, long lda, int M, int N, int rows_per_chunk,
+                                   float* __restrict__ part) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(M, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += a[(long)r * lda + n];
+  part[(long)blockIdx.y * N + n] = s;
+}
+
+__global__ void scale_kernel(const float* __restrict__ in, const float* __restrict__ s, float* __restrict__ out,
+                             long n) {
+  const float f = s[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = in[i] * f;
+}
+
+// ---------------------------------------------------------------------------------------- Adam
+// torch.optim.Adam single-tensor update order: m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float gscale) {
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// tile16 [Mp*T, N] (window row order) <-> row-major [B, T, N]
+__global__ void tile16_from_rows_kernel(const float* __restrict__ rows, float* __restrict__ tiled, int B, int T,
+                                        int N, int to_rows) {
+  const int Bp = (B + 15) / 16 * 16;
+  const long total = (long)Bp * T * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int n = idx % N;
+    const long bt_ = idx / N;
+    const int t = bt_ % T;
+    const int b = bt_ / T;
+    const long mprime = ((long)(b >> 4) * T + t) * 16 + (b & 15);
+    const long off = vts_tile16_offset(mprime, n, N);
+    if (to_rows) {
+      if (b < B) const_cast<float*>(rows)[idx] = tiled[off];
+    } else {
+      tiled[off] = (b < B) ? rows[idx] : 0.f;
+    }
+  }
+}
+
+inline int grid_for(long n) {
+  long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+int vts_ew_reparam_fwd(int mode, const float* mean, const float* logvar, const float* scale, const float* shape,
+                       const float* eps, const float* u, const float* choice, const float* pi, float* z, long B,
+                       int L, hipStream_t st) {
+  const long n = B * L;
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, mode, mean, logvar, scale, shape, eps,
+                     u, choice, pi, z, n, L);
+  VTS_CHECK_LAUNCH("reparam_fwd");
+  return VTS_OK;
+}
+
+int vts_ew_reparam_bwd(int mode, const float* dz, const float* logvar, const float* scale, const float* shape,
+                       const float* eps, const float* u, const float* choice, const float* pi, float* dmean,
+                       float* dlogvar, float* dscale, float* dshape, long B, int L, hipStream_t st) {
+  const long n = B * L;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, mode, dz, logvar, scale, shape, eps,
+                     u, choice, pi, dmean, dlogvar, dscale, dshape, n, L);
+  VTS_CHECK_LAUNCH("reparam_bwd");
+  return VTS_OK;
+}
+
+int vts_ew_elbo_blocks(long nrec, long nlat) {
+  long n = nrec > nlat ? nrec : nlat;
+  long b = (n + 1023) / 1024;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int vts_ew_elbo_fwd(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                    const float* scale, const float* shape, const float* pi, float thr, float beta, long B, int fs,
+                    int L, float* part, float* out10, hipStream_t st) {
+  const long nrec = B * fs, nlat = B * L;
+  const int blocks = vts_ew_elbo_blocks(nrec, nlat);
+  hipLaunchKernelGGL(elbo_partials_kernel, dim3(blocks), dim3(256), 0, st, kind, recon, y, mean, logvar, scale,
+                     shape, thr, nrec, nlat, part);
+  VTS_CHECK_LAUNCH("elbo_partials");
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, pi, beta, B, nrec, nlat,
+                     out10);
+  VTS_CHECK_LAUNCH("elbo_finalize");
+  return VTS_OK;
+}
+
+int vts_ew_elbo_bwd(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                    const float* scale, const float* shape, const float* coef, const float* gout, float thr, long B,
+                    int fs, int L, float* drecon, float* dmean, float* dlogvar, float* dscale, float* dshape,
+                    float* dpi, hipStream_t st) {
+  const long nrec = B * fs, nlat = B * L;
+  hipLaunchKernelGGL(elbo_grads_kernel, dim3(grid_for(nlat > nrec ? nlat : nrec)), dim3(256), 0, st, kind, recon, y,
+                     mean, logvar, scale, shape, coef, gout, thr, nrec, nlat, drecon, dmean, dlogvar, dscale, dshape,
+                     dpi);
+  VTS_CHECK_LAUNCH("elbo_grads");
+  return VTS_OK;
+}
+
+int vts_ew_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, float* mean,
+                         float* rstd, int M, int H, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(vts_cdiv(M, 4)), dim3(256), 0, st, x, ldx, gamma, beta, y, mean,
+                     rstd, M, H, eps);
+  VTS_CHECK_LAUNCH("layernorm_fwd");
+  return VTS_OK;
+}
+
+int vts_ew_layernorm_bwd_blocks(int M) {
+  int b = vts_cdiv(M, 64);
+  if (b > 256) b = 256;
+  return b < 1 ? 1 : b;
+}
+
+int vts_ew_layernorm_bwd(const float* dy, const float* x, long ldx, const float* gamma, const float* mean,
+                         const float* rstd, float* dx, long lddx, float* part, int M, int H, hipStream_t st) {
+  const int blocks = vts_ew_layernorm_bwd_blocks(M);
+  const int rpb = vts_cdiv(M, blocks);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * H * sizeof(float), st, dy, x, ldx, gamma,
+                     mean, rstd, dx, lddx, part, M, H, rpb);
+  VTS_CHECK_LAUNCH("layernorm_bwd");
+  return VTS_OK;
+}
+
+int vts_ew_act_bwd(int kind, const float* dy, const float* y, const float* aux, float scale, float* dpre, long n,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, kind, dy, y, aux, scale, dpre, n);
+  VTS_CHECK_LAUNCH("act_bwd");
+  return VTS_OK;
+}
+
+int vts_ew_colsum_chunks(int M) {
+  int c = vts_cdiv(M, 128);
+  if (c > 64) c = 64;
+  return c < 1 ? 1 : c;
+}
+
+int vts_ew_colsum_rows(const float* a, long lda, int M, int N, float* part, hipStream_t st) {
+  const int chunks = vts_ew_colsum_chunks(M);
+  const int rpc = vts_cdiv(M, chunks);
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3(vts_cdiv(N, 64), chunks), dim3(64), 0, st, a, lda, M, N, rpc, part);
+  VTS_CHECK_LAUNCH("colsum_rows");
+  return VTS_OK;
+}
+
+int vts_ew_scale(const float* in, const float* s, float* out, long n, hipStream_t st) {
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, s, out, n);
+  VTS_CHECK_LAUNCH("scale");
+  return VTS_OK;
+}
+
+int vts_ew_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                float bc1, float bc2_sqrt, float gscale, hipStream_t st) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1,
+                     bc2_sqrt, gscale);
+  VTS_CHECK_LAUNCH("adam");
+  return VTS_OK;
+}
+
+int vts_ew_tile16_convert(const float* rows, float* tiled, int B, int T, int N, int to_rows, hipStream_t st) {
+  const long total = (long)((B + 15) / 16 * 16) * T * N;
+  hipLaunchKernelGGL(tile16_from_rows_kernel, dim3(grid_for(total)), dim3(256), 0, st, rows, tiled, B, T, N,
+                     to_rows);
+  VTS_CHECK_LAUNCH("tile16_convert");
+  return VTS_OK;
+}

@@ -1,0 +1,479 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 fmaf chain, one
+// rounding per product) with LDS-staged 128x128x16 tiles, 4 waves per workgroup, each wave a
+// 64x64 sub-tile = 4x4 MFMA tiles (64 accumulator registers).
+//
+// One kernel template serves every dense contraction of the train step; what changes is how the
+// logical operands A[m][k], B[k][n], C[m][n] map to memory:
+//   A_ROW  A[m][k] = a[row(m)*lda + k]        (k contiguous; optional window row map)
+//   A_COL  A[m][k] = a[k*lda + m]             (m contiguous)
+//   A_T16  A[m][k] = tile16(a)[m][k]          (tile16 layout of an [M, K] matrix)
+//   A_T16T A[m][k] = tile16(a)[k][m]          (tile16 layout of a [K, M] matrix, transposed use)
+//   B_NK   B[k][n] = b[n*ldb + k]             (k contiguous: a Linear weight [N][K])
+//   B_KN   B[k][n] = b[row(k)*ldb + n]        (n contiguous; optional window row map on k)
+//   C_ROW  row-major with bias/activation epilogue, or split-K slabs
+//   C_T16  tile16 layout (+ bias)
+//
+// Window row map (LSTM sequences stored batch-first [B, T, F]): logical row
+// m' = (bt*T + t)*16 + bi  <->  window b = bt*16 + bi at step t (+ tshift), memory row b*T + t.
+// Rows with b >= B or a shifted step outside [0, T) read as zero.
+#include "vts_common.h"
+
+namespace {
+
+enum { A_ROW = 0, A_COL = 1, A_T16 = 2, A_T16T = 3 };
+enum { B_NK = 0, B_KN = 1 };
+enum { C_ROW = 0, C_T16 = 1 };
+
+constexpr int BM = 128, BN = 128, BKT = 16;
+constexpr int LDS_LD = 144;  // 144 % 32 == 16: the (k, k+1) x 16-column b32 fragment reads hit 32 distinct banks
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;          // final output, or slab base when ksplit > 1
+  int M, N, K;
+  long lda, ldb, ldc;
+  // window row maps
+  int a_map, b_map;  // 0 = identity, 1 = window map
+  int T, Bwin;       // steps per window, number of real windows
+  int a_tshift, b_tshift;
+  // epilogue
+  const float* bias0;  // [N] or null
+  const float* bias1;  // [N] or null (second bias, added too)
+  int act;             // 0 none, 1 relu, 2 exp, 3 clamp_min(1e-6), 4 relu * keep * scale
+  const float* keep;   // [M][N] 0/1 keep mask for act 4 (row stride ldc)
+  float keep_scale;
+  float* aux;          // act 3: [M][N] 1.0 where pre-activation >= 1e-6 (gradient passes)
+  int accumulate;      // C += result (ksplit == 1 only)
+  int ksplit;          // >1: grid.z slabs of M*N floats at C
+  int kchunk;          // K elements per split (multiple of 16)
+};
+
+__device__ __forceinline__ long window_row(int m, int T, int Bwin, int tshift, bool& valid) {
+  const int bi = m & 15;
+  const int q = m >> 4;
+  const int t = q % T + tshift;
+  const int b = (q / T) * 16 + bi;
+  valid = (b < Bwin) && (t >= 0) && (t < T);
+  return (long)b * T + t;
+}
+
+// Load 8 consecutive floats p[0..7] with validity count nvalid (elements >= nvalid read as 0),
+// using the widest access the address allows.
+__device__ __forceinline__ void load8(const float* __restrict__ p, int nvalid, float (&v)[8]) {
+  if (nvalid >= 8) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    if ((addr & 15u) == 0) {
+      const float4 x = *reinterpret_cast<const float4*>(p);
+      const float4 y = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+      return;
+    }
+    if ((addr & 7u) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2 x = *reinterpret_cast<const float2*>(p + 2 * i);
+        v[2 * i] = x.x; v[2 * i + 1] = x.y;
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = p[i];
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (i < nvalid) ? p[i] : 0.0f;
+}
+
+template <int AK>
+__device__ __forceinline__ void load_a(const GemmParams& P, int m0, int k0, int kend, int tid, float (&v)[8]) {
+  if constexpr (AK == A_ROW) {
+    const int m = m0 + (tid >> 1);
+    const int k = k0 + (tid & 1) * 8;
+    bool valid = m < P.M;
+    long row = m;
+    if (P.a_map && valid) row = window_row(m, P.T, P.Bwin, P.a_tshift, valid);
+    const int nv = valid ? min(8, kend - k) : 0;
+    if (nv > 0) load8(P.A + row * P.lda + k, nv, v);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+  } else if constexpr (AK == A_COL) {
+    const int k = k0 + (tid >> 4);
+    const int m = m0 + (tid & 15) * 8;
+    const int nv = (k < kend) ? min(8, P.M - m) : 0;
+    if (nv > 0) load8(P.A + (long)k * P.lda + m, nv, v);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+  } else if constexpr (AK == A_T16) {
+    // tile16 of an [M, K] matrix; this thread takes two float4 (rows 4g..4g+3 of column c) of the
+    // block (m-tile m0/16 + blk, k-tile k0/16).
+    const int blk = tid >> 5;
+    const int mt = (m0 >> 4) + blk;
+    const bool valid = (mt * 16 < P.M) && (k0 < kend);
+    if (valid) {
+      const float* p = P.A + ((long)mt * (P.K >> 4) + (k0 >> 4)) * 256 + (tid & 31) * 8;
+      load8(p, 8, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+  } else {  // A_T16T: memory is tile16 of a [K, M] matrix
+    const int blk = tid >> 5;
+    const int mt = (m0 >> 4) + blk;  // column tile of the stored matrix
+    const bool valid = (mt * 16 < P.M) && (k0 < kend);
+    if (valid) {
+      const float* p = P.A + ((long)(k0 >> 4) * (P.M >> 4) + mt) * 256 + (tid & 31) * 8;
+      load8(p, 8, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+  }
+}
+
+template <int AK>
+__device__ __forceinline__ void store_a(float* __restrict__ As, int tid, const float (&v)[8]) {
+  if constexpr (AK == A_ROW) {
+    const int m = tid >> 1;
+    const int kb = (tid & 1) * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) As[(kb + s) * LDS_LD + m] = v[s];
+  } else if constexpr (AK == A_COL) {
+    const int k = tid >> 4;
+    const int m = (tid & 15) * 8;
+    *reinterpret_cast<float4*>(&As[k * LDS_LD + m]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&As[k * LDS_LD + m + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+  } else if constexpr (AK == A_T16) {
+    // float4 j (j = 0,1) is lane l = (tid&31)*2 + j of the block: rows 4g..4g+3 (g = l>>4) of
+    // column c = l&15; the block's column index is k here, its row index is m.
+    const int blk = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int l = (tid & 31) * 2 + j;
+      const int g = l >> 4, c = l & 15;
+      *reinterpret_cast<float4*>(&As[c * LDS_LD + blk * 16 + 4 * g]) =
+          make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    }
+  } else {  // A_T16T: block row index is k, column index is m
+    const int blk = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int l = (tid & 31) * 2 + j;
+      const int g = l >> 4, c = l & 15;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) As[(4 * g + s) * LDS_LD + blk * 16 + c] = v[4 * j + s];
+    }
+  }
+}
+
+template <int BKIND>
+__device__ __forceinline__ void load_b(const GemmParams& P, int n0, int k0, int kend, int tid, float (&v)[8]) {
+  if constexpr (BKIND == B_NK) {
+    const int n = n0 + (tid >> 1);
+    const int k = k0 + (tid & 1) * 8;
+    const int nv = (n < P.N) ? min(8, kend - k) : 0;
+    if (nv > 0) load8(P.B + (long)n * P.ldb + k, nv, v);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+  } else {
+    const int k = k0 + (tid >> 4);
+    const int n = n0 + (tid & 15) * 8;
+    bool valid = k < kend;
+    long row = k;
+    if (P.b_map && valid) row = window_row(k, P.T, P.Bwin, P.b_tshift, valid);
+    const int nv = valid ? min(8, P.N - n) : 0;
+    if (nv > 0) load8(P.B + row * P.ldb + n, nv, v);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+  }
+}
+
+template <int BKIND>
+__device__ __forceinline__ void store_b(float* __restrict__ Bs, int tid, const float (&v)[8]) {
+  if constexpr (BKIND == B_NK) {
+    const int n = tid >> 1;
+    const int kb = (tid & 1) * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) Bs[(kb + s) * LDS_LD + n] = v[s];
+  } else {
+    const int k = tid >> 4;
+    const int n = (tid & 15) * 8;
+    *reinterpret_cast<float4*>(&Bs[k * LDS_LD + n]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&Bs[k * LDS_LD + n + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+template <int AK, int BKIND, int CK>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams P) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][BKT * LDS_LD];  // [buf][A|B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  const int tiles_n = (P.N + BN - 1) / BN;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
+  const int kbeg = blockIdx.z * P.kchunk;
+  const int kend = min(P.K, kbeg + P.kchunk);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float va[8], vb[8];
+  const int nk = (kend - kbeg + BKT - 1) / BKT;
+  if (nk > 0) {
+    load_a<AK>(P, m0, kbeg, kend, tid, va);
+    load_b<BKIND>(P, n0, kbeg, kend, tid, vb);
+    store_a<AK>(lds[0][0], tid, va);
+    store_b<BKIND>(lds[0][1], tid, vb);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      load_a<AK>(P, m0, kbeg + (kt + 1) * BKT, kend, tid, va);
+      load_b<BKIND>(P, n0, kbeg + (kt + 1) * BKT, kend, tid, vb);
+    }
+    const float* As = lds[cur][0];
+    const float* Bs = lds[cur][1];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[(4 * kk + g) * LDS_LD + wm * 64 + i * 16 + r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * kk + g) * LDS_LD + wn * 64 + j * 16 + r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      store_a<AK>(lds[cur ^ 1][0], tid, va);
+      store_b<BKIND>(lds[cur ^ 1][1], tid, vb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  if constexpr (CK == C_T16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mt = (m0 + wm * 64 + i * 16) >> 4;
+      if (mt * 16 >= P.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nbase = n0 + wn * 64 + j * 16;
+        if (nbase >= P.N) continue;
+        f32x4 v = acc[i][j];
+        float bsum = 0.f;
+        if (P.bias0) bsum += P.bias0[nbase + r];
+        if (P.bias1) bsum += P.bias1[nbase + r];
+        v += bsum;
+        float* dst = P.C + ((long)mt * (P.N >> 4) + (nbase >> 4)) * 256 + lane * 4;
+        if (P.accumulate) {
+          const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
+          v += old;
+        }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  } else {
+    float* Cbase = P.C + (P.ksplit > 1 ? (long)blockIdx.z * P.M * P.N : 0);
+    const long ldc = (P.ksplit > 1) ? P.N : P.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r;
+        if (col >= P.N) continue;
+        float bsum = 0.f;
+        if (P.ksplit == 1) {
+          if (P.bias0) bsum += P.bias0[col];
+          if (P.bias1) bsum += P.bias1[col];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = m0 + wm * 64 + i * 16 + 4 * g + reg;
+          if (row >= P.M) continue;
+          float v = acc[i][j][reg] + bsum;
+          if (P.ksplit == 1) {
+            if (P.act == 1) v = fmaxf(v, 0.f);
+            else if (P.act == 2) v = expf(v);
+            else if (P.act == 3) {
+              if (P.aux) P.aux[(long)row * ldc + col] = (v >= 1e-6f) ? 1.f : 0.f;
+              v = fmaxf(v, 1e-6f);
+            } else if (P.act == 4) {
+              v = fmaxf(v, 0.f);
+              if (P.keep) v = v * P.keep[(long)row * ldc + col] * P.keep_scale;
+            }
+            if (P.accumulate) v += Cbase[(long)row * ldc + col];
+          }
+          Cbase[(long)row * ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C.
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
+                                    long ldc, int S, int accumulate) {
+  const long total = (long)M * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[(long)z * total + idx];
+    const long row = idx / N, col = idx % N;
+    float* dst = C + row * ldc + col;
+    *dst = accumulate ? (*dst + s) : s;
+  }
+}
+
+template <int AK, int BKIND, int CK>
+int launch(const GemmParams& P, hipStream_t stream) {
+  const int tiles = vts_cdiv(P.M, BM) * vts_cdiv(P.N, BN);
+  dim3 grid(tiles, 1, P.ksplit);
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKIND, CK>), grid, dim3(256), 0, stream, P);
+  VTS_CHECK_LAUNCH("gemm_f32");
+  return VTS_OK;
+}
+
+}  // namespace
+
+// ---- internal C++ entry points used by vts_api.hip -------------------------------------------
+
+// Number of K splits that fills the chip for a contraction of length K into an M x N output.
+int vts_gemm_pick_ksplit(int M, int N, long K) {
+  const int tiles = vts_cdiv(M, BM) * vts_cdiv(N, BN);
+  if (tiles >= 256 || K <= 512) return 1;
+  long want = (1024 + tiles - 1) / tiles;
+  long maxs = (K + 255) / 256;  // at least 256 contraction elements per split
+  long s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+
+size_t vts_gemm_slab_bytes(int M, int N, int ksplit) {
+  return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0;
+}
+
+static int finish_split(GemmParams P, float* Cfinal, long ldc, int accumulate, hipStream_t stream) {
+  if (P.ksplit <= 1) return VTS_OK;
+  const long total = (long)P.M * P.N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, P.C, Cfinal, P.M, P.N, ldc,
+                     P.ksplit, accumulate);
+  VTS_CHECK_LAUNCH("reduce_slabs");
+  return VTS_OK;
+}
+
+static void set_split(GemmParams& P, int ksplit) {
+  P.ksplit = ksplit < 1 ? 1 : ksplit;
+  long chunk = (P.K + P.ksplit - 1) / P.ksplit;
+  chunk = (chunk + 15) / 16 * 16;
+  P.kchunk = (int)chunk;
+  P.ksplit = (int)((P.K + chunk - 1) / chunk);
+  if (P.ksplit < 1) P.ksplit = 1;
+}
+
+// LSTM input projection: G[tile16 of [Mp, 4H]] = X[window rows] . W^T + b0 + b1
+int vts_gemm_inproj(const float* X, const float* W, const float* b0, const float* b1, float* G, int Bwin, int T,
+                    int Cin, int N4H, hipStream_t stream) {
+  GemmParams P{};
+  const int Bp = (Bwin + 15) / 16 * 16;
+  P.A = X; P.B = W; P.C = G;
+  P.M = Bp * T; P.N = N4H; P.K = Cin;
+  P.lda = Cin; P.ldb = Cin; P.ldc = 0;
+  P.a_map = 1; P.T = T; P.Bwin = Bwin;
+  P.bias0 = b0; P.bias1 = b1;
+  set_split(P, 1);
+  return launch<A_ROW, B_NK, C_T16>(P, stream);
+}
+
+// dX[tile16 of [Mp, Cin]] (+)= dG[tile16 of [Mp, 4H]] . W[4H][Cin]
+int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int T, int Cin, int N4H,
+                       int accumulate, hipStream_t stream) {
+  GemmParams P{};
+  const int Bp = (Bwin + 15) / 16 * 16;
+  P.A = dG; P.B = W; P.C = dX;
+  P.M = Bp * T; P.N = Cin; P.K = N4H;
+  P.ldb = Cin;
+  P.accumulate = accumulate;
+  set_split(P, 1);
+  return launch<A_T16, B_KN, C_T16>(P, stream);
+}
+
+// dW[4H][F] = sum over window rows m' of dG[m'][:]^T . X[window row(m', tshift)][:F]
+int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
+                       int F, long ldx, int N4H, int tshift, int accumulate, hipStream_t stream) {
+  GemmParams P{};
+  const int Bp = (Bwin + 15) / 16 * 16;
+  P.A = dG; P.B = X;
+  P.M = N4H; P.N = F; P.K = Bp * T;
+  P.ldb = ldx; P.ldc = F;
+  P.b_map = 1; P.T = T; P.Bwin = Bwin; P.b_tshift = tshift;
+  set_split(P, ksplit);
+  P.C = (P.ksplit > 1) ? slabs : dW;
+  P.accumulate = (P.ksplit > 1) ? 0 : accumulate;
+  int rc = launch<A_T16T, B_KN, C_ROW>(P, stream);
+  if (rc) return rc;
+  return finish_split(P, dW, F, accumulate, stream);
+}
+
+// Y[M][N] = act(X[M][K] . W[N][K]^T + bias)
+int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
+                        int N, int K, int act, const float* keep, float keep_scale, float* aux,
+                        hipStream_t stream) {
+  GemmParams P{};
+  P.A = X; P.B = W; P.C = Y;
+  P.M = M; P.N = N; P.K = K;
+  P.lda = ldx; P.ldb = K; P.ldc = ldy;
+  P.bias0 = bias; P.act = act; P.keep = keep; P.keep_scale = keep_scale; P.aux = aux;
+  set_split(P, 1);
+  return launch<A_ROW, B_NK, C_ROW>(P, stream);
+}
+
+// dX[M][K] (+)= dY[M][N] . W[N][K]
+int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
+                       int accumulate, hipStream_t stream) {
+  GemmParams P{};
+  P.A = dY; P.B = W; P.C = dX;
+  P.M = M; P.N = K; P.K = N;
+  P.lda = lddy; P.ldb = K; P.ldc = lddx;
+  P.accumulate = accumulate;
+  set_split(P, 1);
+  return launch<A_ROW, B_KN, C_ROW>(P, stream);
+}
+
+// dW[N][K] (+)= dY[M][N]^T . X[M][K]
+int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, float* dW, float* slabs, int ksplit,
+                       int M, int N, int K, int accumulate, hipStream_t stream) {
+  GemmParams P{};
+  P.A = dY; P.B = X;
+  P.M = N; P.N = K; P.K = M;
+  P.lda = lddy; P.ldb = ldx; P.ldc = K;
+  set_split(P, ksplit);
+  P.C = (P.ksplit > 1) ? slabs : dW;
+  P.accumulate = (P.ksplit > 1) ? 0 : accumulate;
+  int rc = launch<A_COL, B_KN, C_ROW>(P, stream);
+  if (rc) return rc;
+  return finish_split(P, dW, K, accumulate, stream);
+}

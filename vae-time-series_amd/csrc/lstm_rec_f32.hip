@@ -1,0 +1,363 @@
+// Persistent LSTM recurrence kernels, fp32 on v_mfma_f32_16x16x4_f32.
+//
+// One workgroup owns 16 windows (one 16-row batch tile) for the whole sequence, so there is no
+// inter-workgroup communication at all: h_t and c_t never leave the CU between steps.  Wave w
+// owns hidden units [w*JPW*16, (w+1)*JPW*16) for ALL four gates, so the cell update is
+// lane-local in the MFMA accumulator layout.  W_hh is streamed from L2 every step in a
+// pre-packed, fragment-ordered image (one coalesced 1 KiB load per MFMA quad).
+//
+// Gate pre-activations / activations / gate gradients live in the tile16 layout
+// (vts_common.h) of a [Bp*T, 4H] matrix with logical row m' = (bt*T + t)*16 + bi.
+#include "vts_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int H>
+struct RecCfg {
+  static constexpr int JT = H / 16;                 // hidden tiles
+  static constexpr int NW = JT >= 4 ? 4 : JT;       // waves per workgroup
+  static constexpr int JPW = JT / NW;               // hidden tiles per wave
+  static constexpr int KQ_F = H / 16;               // k-quads (16 k each) in the forward product
+  static constexpr int KQ_B = (4 * H) / 16;         // k-quads in the backward product
+  static constexpr int LDH = H + 4;                 // LDS row stride of the h tile
+  static constexpr int LDA = 4 * H + 4;             // LDS row stride of the dA tile
+};
+
+// ---- weight packing ---------------------------------------------------------------------------
+// forward image: [wave][kq][jl][gate][lane][s] = W_hh[gate*H + (wave*JPW+jl)*16 + (lane&15)][16*kq + 4*(lane>>4) + s]
+template <int H>
+__global__ void pack_whh_fwd_kernel(const float* __restrict__ W, float* __restrict__ out) {
+  using C = RecCfg<H>;
+  const int total = 4 * H * H;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int s = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    int rest = idx >> 8;
+    const int gate = rest & 3; rest >>= 2;
+    const int jl = rest % C::JPW; rest /= C::JPW;
+    const int kq = rest % C::KQ_F; rest /= C::KQ_F;
+    const int wave = rest;
+    const int row = gate * H + (wave * C::JPW + jl) * 16 + (lane & 15);
+    const int col = 16 * kq + 4 * (lane >> 4) + s;
+    out[idx] = W[row * H + col];
+  }
+}
+
+// backward image: [wave][kq][jl][lane][s] = W_hh[s*H + 4*kq + (lane>>4)][(wave*JPW+jl)*16 + (lane&15)]
+template <int H>
+__global__ void pack_whh_bwd_kernel(const float* __restrict__ W, float* __restrict__ out) {
+  using C = RecCfg<H>;
+  const int total = 4 * H * H;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int s = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    int rest = idx >> 8;
+    const int jl = rest % C::JPW; rest /= C::JPW;
+    const int kq = rest % C::KQ_B; rest /= C::KQ_B;
+    const int wave = rest;
+    const int row = s * H + 4 * kq + (lane >> 4);
+    const int col = (wave * C::JPW + jl) * 16 + (lane & 15);
+    out[idx] = W[row * H + col];
+  }
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+// G     : in  gate pre-activations x.W_ih^T + b (tile16 [Bp*T, 4H]); out activated gates i,f,g,o
+// cseq  : out cell states (tile16 [Bp*T, H])
+// hseq  : out hidden states, row-major [B, T, H]
+// hlast, clast : out optional h_T, c_T row-major [B, H]
+template <int H>
+__global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
+    float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
+    float* __restrict__ clast, const float* __restrict__ Wp, int B, int T) {
+  using C = RecCfg<H>;
+  __shared__ __attribute__((aligned(16))) float hl[2][16 * C::LDH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int bt = blockIdx.x;
+  const int b0 = bt * 16;
+
+  f32x4 c[C::JPW];
+#pragma unroll
+  for (int jl = 0; jl < C::JPW; ++jl) c[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* Wv = reinterpret_cast<const f32x4*>(Wp) + (long)wave * C::KQ_F * C::JPW * 4 * 64 + lane;
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+    f32x4 acc[C::JPW][4];
+#pragma unroll
+    for (int jl = 0; jl < C::JPW; ++jl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[jl][q] = *reinterpret_cast<const f32x4*>(Gt + (long)(q * C::JT + wave * C::JPW + jl) * 256);
+
+    if (t > 0) {
+      const float* hrow = &hl[cur][r * C::LDH + 4 * g];
+#pragma unroll 2
+      for (int kq = 0; kq < C::KQ_F; ++kq) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(hrow + 16 * kq);
+        f32x4 w[C::JPW][4];
+#pragma unroll
+        for (int jl = 0; jl < C::JPW; ++jl)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[jl][q] = Wv[((kq * C::JPW + jl) * 4 + q) * 64];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int jl = 0; jl < C::JPW; ++jl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[jl][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[jl][q][s], acc[jl][q], 0, 0, 0);
+      }
+    }
+
+    // cell update, lane-local: acc[jl][q][reg] is gate q of window row 4g+reg, hidden jt*16+r
+#pragma unroll
+    for (int jl = 0; jl < C::JPW; ++jl) {
+      const int jt = wave * C::JPW + jl;
+      f32x4 gi, gf, gg, go, hv;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        gi[reg] = sigmoidf_(acc[jl][0][reg]);
+        gf[reg] = sigmoidf_(acc[jl][1][reg]);
+        gg[reg] = tanhf(acc[jl][2][reg]);
+        go[reg] = sigmoidf_(acc[jl][3][reg]);
+        c[jl][reg] = gf[reg] * c[jl][reg] + gi[reg] * gg[reg];
+        hv[reg] = go[reg] * tanhf(c[jl][reg]);
+        hl[nxt][(4 * g + reg) * C::LDH + jt * 16 + r] = hv[reg];
+      }
+      *reinterpret_cast<f32x4*>(Gt + (long)(0 * C::JT + jt) * 256) = gi;
+      *reinterpret_cast<f32x4*>(Gt + (long)(1 * C::JT + jt) * 256) = gf;
+      *reinterpret_cast<f32x4*>(Gt + (long)(2 * C::JT + jt) * 256) = gg;
+      *reinterpret_cast<f32x4*>(Gt + (long)(3 * C::JT + jt) * 256) = go;
+      *reinterpret_cast<f32x4*>(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4) = c[jl];
+      if (clast != nullptr && t == T - 1) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int b = b0 + 4 * g + reg;
+          if (b < B) clast[(long)b * H + jt * 16 + r] = c[jl][reg];
+        }
+      }
+    }
+    __syncthreads();
+    // h_t tile -> hseq[b, t, :], whole rows, 16 B per lane
+    for (int idx = tid; idx < 16 * (H / 4); idx += C::NW * 64) {
+      const int row = idx / (H / 4), c4 = idx % (H / 4);
+      const int b = b0 + row;
+      if (b < B) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&hl[nxt][row * C::LDH + 4 * c4]);
+        *reinterpret_cast<f32x4*>(hseq + ((long)b * T + t) * H + 4 * c4) = v;
+        if (hlast != nullptr && t == T - 1) *reinterpret_cast<f32x4*>(hlast + (long)b * H + 4 * c4) = v;
+      }
+    }
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+// G       : in  activated gates (tile16 [Bp*T, 4H]); out gate pre-activation gradients dA
+// cseq    : in  cell states (tile16 [Bp*T, H])
+// dhseq   : in  optional gradient w.r.t. every h_t from the layer above (tile16 [Bp*T, H])
+// dhlast  : in  optional gradient w.r.t. h_T, row-major [B, H]
+// dclast  : in  optional gradient w.r.t. c_T, row-major [B, H]
+// dbpart  : out per-batch-tile column sums of dA: [Bp/16][4H]
+template <int H>
+__global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
+    float* __restrict__ G, const float* __restrict__ cseq, const float* __restrict__ dhseq,
+    const float* __restrict__ dhlast, const float* __restrict__ dclast, float* __restrict__ dbpart,
+    const float* __restrict__ Wp, int B, int T) {
+  using C = RecCfg<H>;
+  extern __shared__ __attribute__((aligned(16))) float dal[];  // [2][16 * LDA]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int bt = blockIdx.x;
+  const int b0 = bt * 16;
+
+  f32x4 dc[C::JPW], dh[C::JPW], dbs[C::JPW][4];
+#pragma unroll
+  for (int jl = 0; jl < C::JPW; ++jl) {
+    dc[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dh[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dbs[jl][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4* Wv = reinterpret_cast<const f32x4*>(Wp) + (long)wave * C::KQ_B * C::JPW * 64 + lane;
+
+  for (int t = T - 1; t >= 0; --t) {
+    const int cur = t & 1;
+    float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+    float* da_s = dal + cur * (16 * C::LDA);
+#pragma unroll
+    for (int jl = 0; jl < C::JPW; ++jl) {
+      const int jt = wave * C::JPW + jl;
+      const f32x4 gi = *reinterpret_cast<const f32x4*>(Gt + (long)(0 * C::JT + jt) * 256);
+      const f32x4 gf = *reinterpret_cast<const f32x4*>(Gt + (long)(1 * C::JT + jt) * 256);
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(Gt + (long)(2 * C::JT + jt) * 256);
+      const f32x4 go = *reinterpret_cast<const f32x4*>(Gt + (long)(3 * C::JT + jt) * 256);
+      const f32x4 ct = *reinterpret_cast<const f32x4*>(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+      f32x4 cp = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t > 0) cp = *reinterpret_cast<const f32x4*>(cseq + ((long)(bt * T + t - 1) * C::JT + jt) * 256 + lane * 4);
+      f32x4 dht = dh[jl];
+      if (dhseq != nullptr)
+        dht += *reinterpret_cast<const f32x4*>(dhseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+      if (t == T - 1) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int b = b0 + 4 * g + reg;
+          if (b < B) {
+            if (dhlast != nullptr) dht[reg] += dhlast[(long)b * H + jt * 16 + r];
+            if (dclast != nullptr) dc[jl][reg] += dclast[(long)b * H + jt * 16 + r];
+          }
+        }
+      }
+      f32x4 dai, daf, dag, dao;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const float tc = tanhf(ct[reg]);
+        const float d_o = dht[reg] * tc;
+        const float dcc = dc[jl][reg] + dht[reg] * go[reg] * (1.f - tc * tc);
+        const float d_i = dcc * gg[reg];
+        const float d_g = dcc * gi[reg];
+        const float d_f = dcc * cp[reg];
+        dc[jl][reg] = dcc * gf[reg];
+        dai[reg] = d_i * gi[reg] * (1.f - gi[reg]);
+        daf[reg] = d_f * gf[reg] * (1.f - gf[reg]);
+        dag[reg] = d_g * (1.f - gg[reg] * gg[reg]);
+        dao[reg] = d_o * go[reg] * (1.f - go[reg]);
+        // k-slot order of the backward product: slot = 4*j + gate
+        *reinterpret_cast<f32x4*>(&da_s[(4 * g + reg) * C::LDA + 4 * (jt * 16 + r)]) =
+            f32x4{dai[reg], daf[reg], dag[reg], dao[reg]};
+      }
+      dbs[jl][0] += dai; dbs[jl][1] += daf; dbs[jl][2] += dag; dbs[jl][3] += dao;
+      *reinterpret_cast<f32x4*>(Gt + (long)(0 * C::JT + jt) * 256) = dai;
+      *reinterpret_cast<f32x4*>(Gt + (long)(1 * C::JT + jt) * 256) = daf;
+      *reinterpret_cast<f32x4*>(Gt + (long)(2 * C::JT + jt) * 256) = dag;
+      *reinterpret_cast<f32x4*>(Gt + (long)(3 * C::JT + jt) * 256) = dao;
+    }
+    if (t == 0) break;  // dh_{-1} is not needed
+    __syncthreads();
+    // dh_rec[16 x H-slice] = dA[16 x 4H] . W_hh[4H x H-slice]
+    f32x4 acc[C::JPW];
+#pragma unroll
+    for (int jl = 0; jl < C::JPW; ++jl) acc[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* arow = &da_s[r * C::LDA + 4 * g];
+#pragma unroll 4
+    for (int kq = 0; kq < C::KQ_B; ++kq) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * kq);
+      f32x4 w[C::JPW];
+#pragma unroll
+      for (int jl = 0; jl < C::JPW; ++jl) w[jl] = Wv[(kq * C::JPW + jl) * 64];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jl = 0; jl < C::JPW; ++jl)
+          acc[jl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[jl][s], acc[jl], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jl = 0; jl < C::JPW; ++jl) dh[jl] = acc[jl];
+  }
+
+  // bias-gradient partials: sum the 4 rows of each lane, then the 4 row groups (lanes r, r+16, r+32, r+48)
+#pragma unroll
+  for (int jl = 0; jl < C::JPW; ++jl) {
+    const int jt = wave * C::JPW + jl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = dbs[jl][q][0] + dbs[jl][q][1] + dbs[jl][q][2] + dbs[jl][q][3];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (g == 0) dbpart[(long)bt * (4 * H) + q * H + jt * 16 + r] = s;
+    }
+  }
+}
+
+__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int N,
+                                       long pitch, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long)p * pitch + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+template <int H>
+int run_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B,
+            int T, hipStream_t stream) {
+  using C = RecCfg<H>;
+  hipLaunchKernelGGL(pack_whh_fwd_kernel<H>, dim3(vts_cdiv(4 * H * H, 256)), dim3(256), 0, stream, W_hh, Wp);
+  VTS_CHECK_LAUNCH("pack_whh_fwd");
+  const int nbt = (B + 15) / 16;
+  hipLaunchKernelGGL(lstm_rec_fwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), 0, stream, G, cseq, hseq, hlast, clast, Wp,
+                     B, T);
+  VTS_CHECK_LAUNCH("lstm_rec_fwd");
+  return VTS_OK;
+}
+
+template <int H>
+int run_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+            float* dbpart, const float* W_hh, float* Wp, int B, int T, hipStream_t stream) {
+  using C = RecCfg<H>;
+  hipLaunchKernelGGL(pack_whh_bwd_kernel<H>, dim3(vts_cdiv(4 * H * H, 256)), dim3(256), 0, stream, W_hh, Wp);
+  VTS_CHECK_LAUNCH("pack_whh_bwd");
+  const int nbt = (B + 15) / 16;
+  const size_t lds = 2ul * 16 * C::LDA * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_bwd_kernel<H>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      vts_set_error("lstm_rec_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return VTS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_rec_bwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), lds, stream, G, cseq, dhseq, dhlast,
+                     dclast, dbpart, Wp, B, T);
+  VTS_CHECK_LAUNCH("lstm_rec_bwd");
+  return VTS_OK;
+}
+
+}  // namespace
+
+bool vts_lstm_hidden_supported(int H) { return H == 16 || H == 32 || H == 64 || H == 128 || H == 256; }
+
+int vts_lstm_rec_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
+                     int B, int T, int H, hipStream_t stream) {
+  switch (H) {
+    case 16: return run_fwd<16>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+    case 32: return run_fwd<32>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+    case 64: return run_fwd<64>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+    case 128: return run_fwd<128>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+    case 256: return run_fwd<256>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+  }
+  vts_set_error("lstm: hidden size %d not supported (16, 32, 64, 128, 256)", H);
+  return VTS_ERR_UNSUPPORTED;
+}
+
+int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+                     float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream) {
+  switch (H) {
+    case 16: return run_bwd<16>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+    case 32: return run_bwd<32>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+    case 64: return run_bwd<64>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+    case 128: return run_bwd<128>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+    case 256: return run_bwd<256>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+  }
+  vts_set_error("lstm: hidden size %d not supported (16, 32, 64, 128, 256)", H);
+  return VTS_ERR_UNSUPPORTED;
+}
+
+int vts_colsum_partials(const float* part, float* out, int nparts, int N, long pitch, int accumulate,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(vts_cdiv(N, 256)), dim3(256), 0, stream, part, out, nparts, N,
+                     pitch, accumulate);
+  VTS_CHECK_LAUNCH("colsum_partials");
+  return VTS_OK;
+}

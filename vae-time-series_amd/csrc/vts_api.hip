@@ -1,0 +1,347 @@
+// extern "C" surface of libvts_hip.so (declared in include/vts.h): argument checks, workspace
+// carving and kernel sequencing.  No device allocation, no synchronisation.
+#include "vts_common.h"
+#include "../../include/vts.h"
+#include <math.h>
+#include <string.h>
+
+// ---- internal entry points (gemm_f32.hip, lstm_rec_f32.hip, elementwise.hip) -------------------
+int vts_gemm_pick_ksplit(int M, int N, long K);
+size_t vts_gemm_slab_bytes(int M, int N, int ksplit);
+int vts_gemm_inproj(const float* X, const float* W, const float* b0, const float* b1, float* G, int Bwin, int T,
+                    int Cin, int N4H, hipStream_t stream);
+int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int T, int Cin, int N4H,
+                       int accumulate, hipStream_t stream);
+int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
+                       int F, long ldx, int N4H, int tshift, int accumulate, hipStream_t stream);
+int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
+                        int N, int K, int act, const float* keep, float keep_scale, float* aux, hipStream_t stream);
+int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
+                       int accumulate, hipStream_t stream);
+int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, float* dW, float* slabs, int ksplit,
+                       int M, int N, int K, int accumulate, hipStream_t stream);
+bool vts_lstm_hidden_supported(int H);
+int vts_lstm_rec_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B, int T,
+                     int H, hipStream_t stream);
+int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+                     float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream);
+int vts_colsum_partials(const float* part, float* out, int nparts, int N, long pitch, int accumulate,
+                        hipStream_t stream);
+int vts_ew_reparam_fwd(int mode, const float* mean, const float* logvar, const float* scale, const float* shape,
+                       const float* eps, const float* u, const float* choice, const float* pi, float* z, long B,
+                       int L, hipStream_t st);
+int vts_ew_reparam_bwd(int mode, const float* dz, const float* logvar, const float* scale, const float* shape,
+                       const float* eps, const float* u, const float* choice, const float* pi, float* dmean,
+                       float* dlogvar, float* dscale, float* dshape, long B, int L, hipStream_t st);
+int vts_ew_elbo_blocks(long nrec, long nlat);
+int vts_ew_elbo_fwd(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                    const float* scale, const float* shape, const float* pi, float thr, float beta, long B, int fs,
+                    int L, float* part, float* out10, hipStream_t st);
+int vts_ew_elbo_bwd(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                    const float* scale, const float* shape, const float* coef, const float* gout, float thr, long B,
+                    int fs, int L, float* drecon, float* dmean, float* dlogvar, float* dscale, float* dshape,
+                    float* dpi, hipStream_t st);
+int vts_ew_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, float* mean,
+                         float* rstd, int M, int H, float eps, hipStream_t st);
+int vts_ew_layernorm_bwd_blocks(int M);
+int vts_ew_layernorm_bwd(const float* dy, const float* x, long ldx, const float* gamma, const float* mean,
+                         const float* rstd, float* dx, long lddx, float* part, int M, int H, hipStream_t st);
+int vts_ew_act_bwd(int kind, const float* dy, const float* y, const float* aux, float scale, float* dpre, long n,
+                   hipStream_t st);
+int vts_ew_colsum_chunks(int M);
+int vts_ew_colsum_rows(const float* a, long lda, int M, int N, float* part, hipStream_t st);
+int vts_ew_scale(const float* in, const float* s, float* out, long n, hipStream_t st);
+int vts_ew_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                float bc1, float bc2_sqrt, float gscale, hipStream_t st);
+int vts_ew_tile16_convert(const float* rows, float* tiled, int B, int T, int N, int to_rows, hipStream_t st);
+
+// ---- error text ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void vts_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline size_t round256(size_t n) { return (n + 255) & ~(size_t)255; }
+static inline long pad16(long b) { return (b + 15) / 16 * 16; }
+
+#define VTS_MODE_CHECK(mode)                                                                       \
+  do {                                                                                             \
+    if ((mode) != 0) {                                                                             \
+      vts_set_error("dtype_mode %d not built into this library (0 = fp32 parity mode)", (int)(mode)); \
+      return VTS_ERR_UNSUPPORTED;                                                                  \
+    }                                                                                              \
+  } while (0)
+
+#define VTS_RC(call)        \
+  do {                      \
+    int rc__ = (call);      \
+    if (rc__) return rc__;  \
+  } while (0)
+
+static bool fits_int(int64_t v) { return v >= 0 && v < (int64_t)2147483647; }
+
+extern "C" {
+
+const char* vts_version(void) { return "vts-hip 0.1 (gfx950, fp32 mfma)"; }
+const char* vts_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ LSTM
+size_t vts_lstm_gates_bytes(int64_t B, int64_t T, int64_t H) { return (size_t)pad16(B) * T * 4 * H * sizeof(float); }
+size_t vts_lstm_cells_bytes(int64_t B, int64_t T, int64_t H) { return (size_t)pad16(B) * T * H * sizeof(float); }
+size_t vts_lstm_seqgrad_bytes(int64_t B, int64_t T, int64_t F) { return (size_t)pad16(B) * T * F * sizeof(float); }
+
+struct LstmWs {
+  float* wpack;   // 4H*H
+  float* dbpart;  // nbt*4H
+  float* slabs;   // wgrad split-K partials
+  int ks_ih, ks_hh;
+  size_t total;
+};
+
+static LstmWs lstm_ws_layout(void* base, int64_t B, int64_t T, int64_t Cin, int64_t H) {
+  LstmWs w{};
+  const long Bp = pad16(B);
+  char* p = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  w.wpack = reinterpret_cast<float*>(p + off); off += round256((size_t)4 * H * H * sizeof(float));
+  w.dbpart = reinterpret_cast<float*>(p + off); off += round256((size_t)(Bp / 16) * 4 * H * sizeof(float));
+  w.ks_ih = vts_gemm_pick_ksplit((int)(4 * H), (int)Cin, Bp * T);
+  w.ks_hh = vts_gemm_pick_ksplit((int)(4 * H), (int)H, Bp * T);
+  const size_t s1 = vts_gemm_slab_bytes((int)(4 * H), (int)Cin, w.ks_ih);
+  const size_t s2 = vts_gemm_slab_bytes((int)(4 * H), (int)H, w.ks_hh);
+  w.slabs = reinterpret_cast<float*>(p + off); off += round256(s1 > s2 ? s1 : s2);
+  w.total = off;
+  return w;
+}
+
+size_t vts_lstm_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H) {
+  return lstm_ws_layout(nullptr, B, T, Cin, H).total;
+}
+
+static int lstm_check(int64_t B, int64_t T, int64_t Cin, int64_t H) {
+  VTS_REQUIRE(B > 0 && T > 0 && Cin > 0, "lstm: B, T, Cin must be positive (got %ld, %ld, %ld)", (long)B, (long)T,
+              (long)Cin);
+  if (!vts_lstm_hidden_supported((int)H)) {
+    vts_set_error("lstm: hidden size %ld not supported (16, 32, 64, 128, 256)", (long)H);
+    return VTS_ERR_UNSUPPORTED;
+  }
+  VTS_REQUIRE(fits_int(pad16(B) * T) && fits_int(pad16(B) * T * 4 * H / 16), "lstm: B*T too large");
+  return VTS_OK;
+}
+
+int vts_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                       float* gates, float* cells, float* hseq, float* h_last, float* c_last, void* workspace,
+                       size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode,
+                       vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, Cin, H));
+  VTS_REQUIRE(x && w_ih && w_hh && gates && cells && hseq && workspace, "lstm_layer_fwd: null pointer");
+  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(hseq) && vts_aligned16(workspace) &&
+                  vts_aligned16(w_hh),
+              "lstm_layer_fwd: gates, cells, hseq, w_hh and workspace must be 16-byte aligned");
+  const LstmWs ws = lstm_ws_layout(workspace, B, T, Cin, H);
+  VTS_REQUIRE(workspace_bytes >= ws.total, "lstm_layer_fwd: workspace %zu B < required %zu B", workspace_bytes,
+              ws.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  VTS_RC(vts_gemm_inproj(x, w_ih, b_ih, b_hh, gates, (int)B, (int)T, (int)Cin, (int)(4 * H), st));
+  VTS_RC(vts_lstm_rec_fwd(gates, cells, hseq, h_last, c_last, w_hh, ws.wpack, (int)B, (int)T, (int)H, st));
+  return VTS_OK;
+}
+
+int vts_lstm_layer_bwd(const float* x, const float* hseq, const float* w_ih, const float* w_hh, float* gates,
+                       const float* cells, const float* dh_seq_t16, const float* dh_last, const float* dc_last,
+                       float* dx_t16, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int accumulate,
+                       void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H,
+                       int dtype_mode, vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, Cin, H));
+  VTS_REQUIRE(x && hseq && w_ih && w_hh && gates && cells && workspace, "lstm_layer_bwd: null pointer");
+  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(workspace) &&
+                  (!dh_seq_t16 || vts_aligned16(dh_seq_t16)) && (!dx_t16 || vts_aligned16(dx_t16)),
+              "lstm_layer_bwd: tile16 buffers and workspace must be 16-byte aligned");
+  VTS_REQUIRE(dx_t16 == nullptr || (Cin % 16) == 0, "lstm_layer_bwd: dx needs Cin %% 16 == 0 (got %ld)", (long)Cin);
+  const LstmWs ws = lstm_ws_layout(workspace, B, T, Cin, H);
+  VTS_REQUIRE(workspace_bytes >= ws.total, "lstm_layer_bwd: workspace %zu B < required %zu B", workspace_bytes,
+              ws.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nbt = (int)(pad16(B) / 16);
+  VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, ws.dbpart, w_hh, ws.wpack, (int)B, (int)T,
+                          (int)H, st));
+  if (db_ih) VTS_RC(vts_colsum_partials(ws.dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));
+  if (db_hh) VTS_RC(vts_colsum_partials(ws.dbpart, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
+  if (dx_t16) VTS_RC(vts_gemm_dgrad_t16(gates, w_ih, dx_t16, (int)B, (int)T, (int)Cin, (int)(4 * H), 0, st));
+  if (dw_ih)
+    VTS_RC(vts_gemm_wgrad_t16(gates, x, dw_ih, ws.slabs, ws.ks_ih, (int)B, (int)T, (int)Cin, Cin, (int)(4 * H), 0,
+                              accumulate, st));
+  if (dw_hh)
+    VTS_RC(vts_gemm_wgrad_t16(gates, hseq, dw_hh, ws.slabs, ws.ks_hh, (int)B, (int)T, (int)H, H, (int)(4 * H), -1,
+                              accumulate, st));
+  return VTS_OK;
+}
+
+int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows, vts_stream_t stream) {
+  VTS_REQUIRE(rows && tiled && B > 0 && T > 0 && N > 0 && (N % 16) == 0, "tile16_convert: bad arguments");
+  return vts_ew_tile16_convert(rows, tiled, (int)B, (int)T, (int)N, to_rows, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------- Linear
+int vts_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t M, int64_t N,
+                   int64_t K, int act, const float* keep, float keep_scale, float* aux, int dtype_mode,
+                   vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0 && ldx >= K, "linear_fwd: bad arguments");
+  VTS_REQUIRE(act >= 0 && act <= 4, "linear_fwd: unknown activation %d", act);
+  VTS_REQUIRE(fits_int(M) && fits_int(N) && fits_int(K), "linear_fwd: dimension too large");
+  return vts_gemm_linear_fwd(x, ldx, w, bias, y, N, (int)M, (int)N, (int)K, act, keep, keep_scale, aux,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+
+struct LinWs {
+  float* dpre;
+  float* slabs;
+  float* colpart;
+  int ksplit;
+  size_t total;
+};
+
+static LinWs lin_ws_layout(void* base, int64_t M, int64_t N, int64_t K) {
+  LinWs w{};
+  char* p = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  w.dpre = reinterpret_cast<float*>(p + off); off += round256((size_t)M * N * sizeof(float));
+  w.ksplit = vts_gemm_pick_ksplit((int)N, (int)K, M);
+  w.slabs = reinterpret_cast<float*>(p + off); off += round256(vts_gemm_slab_bytes((int)N, (int)K, w.ksplit));
+  w.colpart = reinterpret_cast<float*>(p + off); off += round256((size_t)vts_ew_colsum_chunks((int)M) * N * sizeof(float));
+  w.total = off;
+  return w;
+}
+
+size_t vts_linear_bwd_workspace_bytes(int64_t M, int64_t N, int64_t K) { return lin_ws_layout(nullptr, M, N, K).total; }
+
+int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, float keep_scale, const float* x,
+                   int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate, float* dw, float* db,
+                   int param_accumulate, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
+                   int dtype_mode, vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_REQUIRE(dy && x && w && workspace && M > 0 && N > 0 && K > 0, "linear_bwd: bad arguments");
+  VTS_REQUIRE(act >= 0 && act <= 4, "linear_bwd: unknown activation %d", act);
+  VTS_REQUIRE(act == 0 || y != nullptr, "linear_bwd: activation %d needs the forward output y", act);
+  VTS_REQUIRE(act != 3 || aux != nullptr, "linear_bwd: clamp needs the aux mask written by linear_fwd");
+  const LinWs ws = lin_ws_layout(workspace, M, N, K);
+  VTS_REQUIRE(workspace_bytes >= ws.total, "linear_bwd: workspace %zu B < required %zu B", workspace_bytes, ws.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float* dpre = dy;
+  if (act != 0) {
+    VTS_RC(vts_ew_act_bwd(act, dy, y, aux, keep_scale, ws.dpre, M * N, st));
+    dpre = ws.dpre;
+  }
+  if (dx) VTS_RC(vts_gemm_linear_dx(dpre, N, w, dx, lddx, (int)M, (int)N, (int)K, dx_accumulate, st));
+  if (dw)
+    VTS_RC(vts_gemm_linear_dw(dpre, N, x, ldx, dw, ws.slabs, ws.ksplit, (int)M, (int)N, (int)K, param_accumulate, st));
+  if (db) {
+    VTS_RC(vts_ew_colsum_rows(dpre, N, (int)M, (int)N, ws.colpart, st));
+    VTS_RC(vts_colsum_partials(ws.colpart, db, vts_ew_colsum_chunks((int)M), (int)N, N, param_accumulate, st));
+  }
+  return VTS_OK;
+}
+
+// ------------------------------------------------------------------------------------- LayerNorm
+int vts_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, float* mean,
+                      float* rstd, int64_t M, int64_t H, float eps, vts_stream_t stream) {
+  VTS_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0 && H > 0 && ldx >= H, "layernorm_fwd: bad arguments");
+  return vts_ew_layernorm_fwd(x, ldx, gamma, beta, y, mean, rstd, (int)M, (int)H, eps,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t vts_layernorm_bwd_workspace_bytes(int64_t M, int64_t H) {
+  return round256((size_t)vts_ew_layernorm_bwd_blocks((int)M) * 2 * H * sizeof(float));
+}
+
+int vts_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                      const float* rstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, int param_accumulate,
+                      void* workspace, size_t workspace_bytes, int64_t M, int64_t H, vts_stream_t stream) {
+  VTS_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace && M > 0 && H > 0, "layernorm_bwd: bad arguments");
+  VTS_REQUIRE(H <= 4096, "layernorm_bwd: H %ld too large", (long)H);
+  VTS_REQUIRE(workspace_bytes >= vts_layernorm_bwd_workspace_bytes(M, H), "layernorm_bwd: workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  VTS_RC(vts_ew_layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx, lddx, part, (int)M, (int)H, st));
+  const int blocks = vts_ew_layernorm_bwd_blocks((int)M);
+  // partials are [blk][2][H]
+  if (dgamma) VTS_RC(vts_colsum_partials(part, dgamma, blocks, (int)H, 2 * H, param_accumulate, st));
+  if (dbeta) VTS_RC(vts_colsum_partials(part + H, dbeta, blocks, (int)H, 2 * H, param_accumulate, st));
+  return VTS_OK;
+}
+
+// ----------------------------------------------------------------------------- reparam and ELBO
+int vts_reparam_fwd(int family, const float* mean, const float* logvar, const float* scale, const float* shape,
+                    const float* eps, const float* u, const float* choice, const float* pi, float* z, int64_t B,
+                    int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && z && B > 0 && L > 0, "reparam_fwd: bad arguments");
+  VTS_REQUIRE(family == VTS_GPD || (mean && logvar && eps), "reparam_fwd: gaussian inputs missing");
+  VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape && u), "reparam_fwd: gpd inputs missing");
+  VTS_REQUIRE(family != VTS_MIXTURE || (choice && pi), "reparam_fwd: mixture needs choice and pi");
+  return vts_ew_reparam_fwd(family, mean, logvar, scale, shape, eps, u, choice, pi, z, B, (int)L,
+                            reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_reparam_bwd(int family, const float* dz, const float* logvar, const float* scale, const float* shape,
+                    const float* eps, const float* u, const float* choice, const float* pi, float* dmean,
+                    float* dlogvar, float* dscale, float* dshape, int64_t B, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && dz && B > 0 && L > 0, "reparam_bwd: bad arguments");
+  VTS_REQUIRE(family == VTS_GPD || (logvar && eps && dmean && dlogvar), "reparam_bwd: gaussian buffers missing");
+  VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape && u && dscale && dshape), "reparam_bwd: gpd buffers missing");
+  VTS_REQUIRE(family != VTS_MIXTURE || (choice && pi), "reparam_bwd: mixture needs choice and pi");
+  return vts_ew_reparam_bwd(family, dz, logvar, scale, shape, eps, u, choice, pi, dmean, dlogvar, dscale, dshape, B,
+                            (int)L, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t vts_elbo_workspace_bytes(int64_t B, int64_t fs, int64_t L) {
+  return round256((size_t)vts_ew_elbo_blocks(B * fs, B * L) * 5 * sizeof(float));
+}
+
+int vts_elbo_fwd(int family, const float* recon, const float* y, const float* mean, const float* logvar,
+                 const float* scale, const float* shape, const float* pi, float threshold, float beta, float* state,
+                 void* workspace, size_t workspace_bytes, int64_t B, int64_t fs, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && recon && y && state && workspace && B > 0 && fs > 0 && L > 0,
+              "elbo_fwd: bad arguments");
+  VTS_REQUIRE(family == VTS_GPD || (mean && logvar), "elbo_fwd: gaussian inputs missing");
+  VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape), "elbo_fwd: gpd inputs missing");
+  VTS_REQUIRE(family != VTS_MIXTURE || pi, "elbo_fwd: mixture needs pi");
+  VTS_REQUIRE(workspace_bytes >= vts_elbo_workspace_bytes(B, fs, L), "elbo_fwd: workspace too small");
+  return vts_ew_elbo_fwd(family, recon, y, mean, logvar, scale, shape, pi, threshold, beta, B, (int)fs, (int)L,
+                         reinterpret_cast<float*>(workspace), state, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_elbo_bwd(int family, const float* recon, const float* y, const float* mean, const float* logvar,
+                 const float* scale, const float* shape, const float* state, const float* grad_out, float threshold,
+                 float* drecon, float* dmean, float* dlogvar, float* dscale, float* dshape, float* dpi, int64_t B,
+                 int64_t fs, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && recon && y && state && drecon && B > 0 && fs > 0 && L > 0,
+              "elbo_bwd: bad arguments");
+  VTS_REQUIRE(family == VTS_GPD || (mean && logvar && dmean && dlogvar), "elbo_bwd: gaussian buffers missing");
+  VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape && dscale && dshape), "elbo_bwd: gpd buffers missing");
+  return vts_ew_elbo_bwd(family, recon, y, mean, logvar, scale, shape, state, grad_out, threshold, B, (int)fs, (int)L,
+                         drecon, dmean, dlogvar, dscale, dshape, dpi, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------ Adam
+int vts_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                  float lr, float beta1, float beta2, float eps, float grad_scale, vts_stream_t stream) {
+  VTS_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  return vts_ew_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
+                     grad_scale, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream) {
+  VTS_REQUIRE(in && scalar && out && n > 0, "scale: bad arguments");
+  return vts_ew_scale(in, scalar, out, n, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

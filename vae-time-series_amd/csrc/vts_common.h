@@ -1,0 +1,47 @@
+// Shared declarations for the vts HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#define VTS_OK 0
+#define VTS_ERR_ARG 1      // bad shape / pointer / alignment
+#define VTS_ERR_HIP 2      // a HIP runtime call failed
+#define VTS_ERR_UNSUPPORTED 3
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Thread-local message for vts_last_error().
+void vts_set_error(const char* fmt, ...);
+
+#define VTS_REQUIRE(cond, ...)                    \
+  do {                                            \
+    if (!(cond)) {                                \
+      vts_set_error(__VA_ARGS__);                 \
+      return VTS_ERR_ARG;                         \
+    }                                             \
+  } while (0)
+
+#define VTS_CHECK_LAUNCH(what)                                               \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      vts_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));  \
+      return VTS_ERR_HIP;                                                    \
+    }                                                                        \
+  } while (0)
+
+static inline bool vts_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int vts_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// "tile16" layout of a logical [M', N] fp32 matrix (M' and N multiples of 16): 16x16 blocks,
+// block (mt, nt) at ((mt * N/16) + nt) * 256 floats; inside a block element (r, c) sits at
+// ((r >> 2) * 16 + c) * 4 + (r & 3).  That is exactly the C/D register image of
+// v_mfma_f32_16x16x4_f32 (lane l = (r>>2)*16 + c holds rows 4*(l>>4)..+3 of column l&15), so a
+// wave stores or loads one block as 64 lanes x 16 B, fully coalesced, and the same float4 is
+// also a ready-made A fragment (4 consecutive k for one column) for a product that contracts
+// over the block's row index.
+__host__ __device__ static inline long vts_tile16_offset(long m, long n, long N) {
+  return ((m >> 4) * (N >> 4) + (n >> 4)) * 256 + ((((m & 15) >> 2) * 16 + (n & 15)) << 2) + (m & 3);
+}

@@ -1,0 +1,102 @@
+"""ctypes binding of libvts_hip.so (the C ABI declared in include/vts.h).
+
+There is no fallback: if the shared library is missing, or a call is made with tensors that
+are not on a ROCm device, this module raises.  Tensors are passed as raw device pointers
+(``Tensor.data_ptr()``) together with torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvts_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_EXP, ACT_CLAMP_MIN, ACT_RELU_DROPOUT = 0, 1, 2, 3, 4
+GAUSSIAN, GPD, MIXTURE = 0, 1, 2
+FAMILY = {"gaussian": GAUSSIAN, "gpd": GPD, "mixture": MIXTURE}
+
+_i64, _f32, _int, _ptr, _sz = C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vts.h one to one
+SIGNATURES = {
+    "vts_version": (C.c_char_p, []),
+    "vts_last_error": (C.c_char_p, []),
+    "vts_lstm_gates_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_lstm_cells_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_lstm_seqgrad_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_lstm_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "vts_lstm_layer_fwd": (_int, [_ptr] * 10 + [_ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_layer_bwd": (_int, [_ptr] * 14 + [_int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_tile16_convert": (_int, [_ptr, _ptr, _i64, _i64, _i64, _int, _ptr]),
+    "vts_linear_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _f32, _ptr, _int, _ptr]),
+    "vts_linear_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_linear_bwd": (_int, [_ptr, _ptr, _ptr, _int, _f32, _ptr, _i64, _ptr, _ptr, _i64, _int, _ptr, _ptr, _int,
+                              _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
+    "vts_layernorm_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr]),
+    "vts_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
+    "vts_layernorm_bwd": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _ptr, _sz,
+                                 _i64, _i64, _ptr]),
+    "vts_reparam_fwd": (_int, [_int] + [_ptr] * 9 + [_i64, _i64, _ptr]),
+    "vts_reparam_bwd": (_int, [_int] + [_ptr] * 12 + [_i64, _i64, _ptr]),
+    "vts_elbo_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_elbo_fwd": (_int, [_int] + [_ptr] * 7 + [_f32, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64, _ptr]),
+    "vts_elbo_bwd": (_int, [_int] + [_ptr] * 8 + [_f32] + [_ptr] * 6 + [_i64, _i64, _i64, _ptr]),
+    "vts_adam_step": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr]),
+    "vts_scale": (_int, [_ptr, _ptr, _ptr, _i64, _ptr]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C vae-time-series_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU or PyTorch fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def version() -> str:
+    return load().vts_version().decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {load().vts_last_error().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a tensor (None -> NULL).  Refuses anything not on a GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vts kernels run on a ROCm device only: got a tensor on " + str(t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"vts kernels take float32 tensors, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Scratch bytes from torch's caching allocator (16-byte aligned by construction)."""
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def wptr(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())

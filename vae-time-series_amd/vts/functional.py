@@ -1,0 +1,324 @@
+"""autograd.Functions over the vts C ABI: the torch call sites of the reference's train step
+(nn.LSTM, nn.Linear+activation, nn.LayerNorm, reparameterize*, loss_function) as drop-in
+differentiable ops whose forward and backward are HIP kernels.
+
+Reference call sites (vae-models/): gaussian-lstm-DE.py:28-31,43-45,55-58,66-70 ;
+gpd-lstm-DE.py:10-12,27-33,45-47,67-71 ; mixture-vae-DE.py:10-18,60-68,81-83,94-107,115-130.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+DROP_P = 0.3
+_MODE = 0  # dtype_mode of the C ABI: 0 = fp32 matrix-core arithmetic
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------- LSTM
+class _LSTMStack(torch.autograd.Function):
+    """All layers of nn.LSTM(batch_first=True), zero initial state.
+    Returns (output [B,T,H], h_n [layers,B,H], c_n [layers,B,H])."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, num_layers: int, *weights: torch.Tensor):
+        lib = L.load()
+        x = x.contiguous()
+        B, T, C0 = x.shape
+        H = weights[1].shape[1]
+        dev = x.device
+        h_n = torch.empty(num_layers, B, H, device=dev, dtype=torch.float32)
+        c_n = torch.empty(num_layers, B, H, device=dev, dtype=torch.float32)
+        saved: List[torch.Tensor] = []
+        inp = x
+        for k in range(num_layers):
+            w_ih, w_hh, b_ih, b_hh = [w.contiguous() for w in weights[4 * k:4 * k + 4]]
+            cin = inp.shape[2]
+            gates = L.workspace(lib.vts_lstm_gates_bytes(B, T, H), dev)
+            cells = L.workspace(lib.vts_lstm_cells_bytes(B, T, H), dev)
+            hseq = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+            ws_bytes = lib.vts_lstm_workspace_bytes(B, T, cin, H)
+            ws = L.workspace(ws_bytes, dev)
+            L.check(lib.vts_lstm_layer_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh),
+                                           L.wptr(gates), L.wptr(cells), L.ptr(hseq), L.ptr(h_n[k]), L.ptr(c_n[k]),
+                                           L.wptr(ws), ws_bytes, B, T, cin, H, _MODE, L.stream()),
+                    "vts_lstm_layer_fwd")
+            saved += [inp, gates, cells, hseq]
+            inp = hseq
+        ctx.num_layers = num_layers
+        ctx.dims = (B, T, C0, H)
+        ctx.save_for_backward(*saved, *weights)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable()
+        return inp, h_n, c_n
+
+    @staticmethod
+    def backward(ctx, g_out, g_hn, g_cn):
+        lib = L.load()
+        nl = ctx.num_layers
+        B, T, C0, H = ctx.dims
+        tensors = ctx.saved_tensors
+        saved, weights = tensors[:4 * nl], tensors[4 * nl:]
+        dev = saved[0].device
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * nl)
+        dh_seq = None
+        if g_out is not None:
+            dh_seq = L.workspace(lib.vts_lstm_seqgrad_bytes(B, T, H), dev)
+            L.check(lib.vts_tile16_convert(L.ptr(g_out.contiguous()), L.wptr(dh_seq), B, T, H, 0, L.stream()),
+                    "vts_tile16_convert")
+        dx0 = None
+        for k in reversed(range(nl)):
+            inp, gates, cells, hseq = saved[4 * k:4 * k + 4]
+            w_ih, w_hh = weights[4 * k].contiguous(), weights[4 * k + 1].contiguous()
+            cin = inp.shape[2]
+            need_dx = (k > 0) or ctx.needs_input_grad[0]
+            if need_dx and cin % 16 != 0:
+                raise NotImplementedError("gradient w.r.t. the LSTM input needs input_size % 16 == 0")
+            dx = L.workspace(lib.vts_lstm_seqgrad_bytes(B, T, cin), dev) if need_dx else None
+            dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+            db_ih = torch.empty(4 * H, device=dev, dtype=torch.float32)
+            db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
+            dh_last = _c(g_hn[k]) if g_hn is not None else None
+            dc_last = _c(g_cn[k]) if g_cn is not None else None
+            ws_bytes = lib.vts_lstm_workspace_bytes(B, T, cin, H)
+            ws = L.workspace(ws_bytes, dev)
+            L.check(lib.vts_lstm_layer_bwd(L.ptr(inp), L.ptr(hseq), L.ptr(w_ih), L.ptr(w_hh), L.wptr(gates),
+                                           L.wptr(cells), None if dh_seq is None else L.wptr(dh_seq),
+                                           L.ptr(dh_last), L.ptr(dc_last), None if dx is None else L.wptr(dx),
+                                           L.ptr(dw_ih), L.ptr(dw_hh), L.ptr(db_ih), L.ptr(db_hh), 0,
+                                           L.wptr(ws), ws_bytes, B, T, cin, H, _MODE, L.stream()),
+                    "vts_lstm_layer_bwd")
+            grads[4 * k:4 * k + 4] = [dw_ih, dw_hh, db_ih, db_hh]
+            dh_seq = dx
+            if k == 0:
+                dx0 = dx
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B, T, C0, device=dev, dtype=torch.float32)
+            L.check(lib.vts_tile16_convert(L.ptr(gx), L.wptr(dx0), B, T, C0, 1, L.stream()), "vts_tile16_convert")
+        return (gx, None, *grads)
+
+
+def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int
+         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(output, h_n, c_n) of a stacked batch-first LSTM; ``weights`` = [w_ih, w_hh, b_ih, b_hh] per layer."""
+    return _LSTMStack.apply(x, num_layers, *weights)
+
+
+# ----------------------------------------------------------------------------------- Linear
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: int, keep):
+        lib = L.load()
+        if x.dim() != 2 or x.stride(1) != 1:
+            x = x.reshape(-1, x.shape[-1]).contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        weight = weight.contiguous()
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        aux = torch.empty(M, N, device=x.device, dtype=torch.float32) if act == L.ACT_CLAMP_MIN else None
+        if act == L.ACT_RELU_DROPOUT and keep is None:
+            act = L.ACT_RELU  # eval mode
+        keep = _c(keep)
+        scale = 1.0 / (1.0 - DROP_P)
+        L.check(lib.vts_linear_fwd(L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(_c(bias)), L.ptr(y), M, N, K, act,
+                                   L.ptr(keep), scale, L.ptr(aux), _MODE, L.stream()), "vts_linear_fwd")
+        ctx.act = act
+        ctx.scale = scale
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y, aux)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, weight, y, aux = ctx.saved_tensors
+        M, K = x.shape
+        N = weight.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty(M, K, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N, device=x.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        ws_bytes = lib.vts_linear_bwd_workspace_bytes(M, N, K)
+        ws = L.workspace(ws_bytes, x.device)
+        L.check(lib.vts_linear_bwd(L.ptr(dy), L.ptr(y), L.ptr(aux), ctx.act, ctx.scale, L.ptr(x), x.stride(0),
+                                   L.ptr(weight), L.ptr(dx), K, 0, L.ptr(dw), L.ptr(db), 0, L.wptr(ws), ws_bytes,
+                                   M, N, K, _MODE, L.stream()), "vts_linear_bwd")
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, act: int = L.ACT_NONE, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ weight.T + bias) with the activation (and dropout mask) fused into the GEMM epilogue."""
+    return _Linear.apply(x, weight, bias, act, keep)
+
+
+# -------------------------------------------------------------------------------- LayerNorm
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        lib = L.load()
+        if x.dim() != 2 or x.stride(1) != 1:
+            x = x.reshape(-1, x.shape[-1]).contiguous()
+        M, H = x.shape
+        y = torch.empty(M, H, device=x.device, dtype=torch.float32)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        L.check(lib.vts_layernorm_fwd(L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean),
+                                      L.ptr(rstd), M, H, eps, L.stream()), "vts_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, gamma, mean, rstd = ctx.saved_tensors
+        M, H = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty(M, H, device=x.device, dtype=torch.float32)
+        dgamma = torch.empty(H, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(H, device=x.device, dtype=torch.float32)
+        ws_bytes = lib.vts_layernorm_bwd_workspace_bytes(M, H)
+        ws = L.workspace(ws_bytes, x.device)
+        L.check(lib.vts_layernorm_bwd(L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                                      L.ptr(dx), H, L.ptr(dgamma), L.ptr(dbeta), 0, L.wptr(ws), ws_bytes, M, H,
+                                      L.stream()), "vts_layernorm_bwd")
+        return dx, dgamma, dbeta, None
+
+
+def layer_norm(x, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ---------------------------------------------------------------------------------- reparam
+class _Reparam(torch.autograd.Function):
+    """family 0: (mean, logvar, eps); 1: (scale, shape, u); 2: all + choice + pi_params."""
+
+    @staticmethod
+    def forward(ctx, family: int, mean, logvar, scale, shape, eps, u, choice, pi):
+        lib = L.load()
+        ref = mean if mean is not None else scale
+        B, Ld = ref.shape
+        mean, logvar, scale, shape, eps, u, choice = [_c(t) for t in (mean, logvar, scale, shape, eps, u, choice)]
+        pi_d = None if pi is None else pi.detach().contiguous()
+        z = torch.empty(B, Ld, device=ref.device, dtype=torch.float32)
+        L.check(lib.vts_reparam_fwd(family, L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape), L.ptr(eps),
+                                    L.ptr(u), L.ptr(choice), L.ptr(pi_d), L.ptr(z), B, Ld, L.stream()),
+                "vts_reparam_fwd")
+        ctx.family = family
+        ctx.save_for_backward(logvar, scale, shape, eps, u, choice, pi_d)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = L.load()
+        logvar, scale, shape, eps, u, choice, pi_d = ctx.saved_tensors
+        dz = dz.contiguous()
+        B, Ld = dz.shape
+        fam = ctx.family
+        new = lambda: torch.empty(B, Ld, device=dz.device, dtype=torch.float32)
+        dmean = dlogvar = dscale = dshape = None
+        if fam != L.GPD:
+            dmean, dlogvar = new(), new()
+        if fam != L.GAUSSIAN:
+            dscale, dshape = new(), new()
+        L.check(lib.vts_reparam_bwd(fam, L.ptr(dz), L.ptr(logvar), L.ptr(scale), L.ptr(shape), L.ptr(eps), L.ptr(u),
+                                    L.ptr(choice), L.ptr(pi_d), L.ptr(dmean), L.ptr(dlogvar), L.ptr(dscale),
+                                    L.ptr(dshape), B, Ld, L.stream()), "vts_reparam_bwd")
+        return None, dmean, dlogvar, dscale, dshape, None, None, None, None
+
+
+def reparameterize_gaussian(mean, logvar, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mean + eps * exp(0.5 * logvar); eps ~ N(0,1) drawn on the device when not fed in."""
+    if eps is None:
+        eps = torch.randn_like(mean)
+    return _Reparam.apply(L.GAUSSIAN, mean, logvar, None, None, eps, None, None, None)
+
+
+def reparameterize_gpd(scale, shape, size=None, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """scale / shape * ((1 - u) ** (-shape) - 1); u ~ U[0,1) drawn on the device when not fed in
+    (the reference draws it on the CPU, gpd-lstm-DE.py:11, which is why it cannot leave the CPU)."""
+    if u is None:
+        u = torch.rand(scale.shape if size is None else size, device=scale.device)
+    return _Reparam.apply(L.GPD, None, None, scale, shape, None, u, None, None)
+
+
+def reparameterize_mixture(mean, logvar, scale, shape, pi_params, choice=None, eps=None, u=None) -> torch.Tensor:
+    """Row i is the Gaussian sample iff choice[i] < softmax(pi_params)[0], else the GPD sample
+    (mixture-vae-DE.py:94-107 without the per-row Python loop).  Draw order when noise is not fed
+    in follows the reference: choice, eps, u."""
+    if choice is None:
+        choice = torch.rand(mean.shape[0], device=mean.device)
+    if eps is None:
+        eps = torch.randn_like(mean)
+    if u is None:
+        u = torch.rand(mean.shape, device=mean.device)
+    return _Reparam.apply(L.MIXTURE, mean, logvar, scale, shape, eps, u, choice, pi_params)
+
+
+# ------------------------------------------------------------------------------------- ELBO
+class _Elbo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, family: int, recon, y, mean, logvar, scale, shape, pi, threshold: float, beta: float):
+        lib = L.load()
+        recon, y = recon.contiguous(), y.contiguous()
+        B = recon.shape[0]
+        fs = recon.numel() // B
+        ref = mean if mean is not None else scale
+        Ld = ref.shape[1]
+        mean, logvar, scale, shape, pi = [_c(t) for t in (mean, logvar, scale, shape, pi)]
+        state = torch.empty(16, device=recon.device, dtype=torch.float32)
+        ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
+        ws = L.workspace(ws_bytes, recon.device)
+        L.check(lib.vts_elbo_fwd(family, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale),
+                                 L.ptr(shape), L.ptr(pi), threshold, beta, L.ptr(state), L.wptr(ws), ws_bytes, B, fs,
+                                 Ld, L.stream()), "vts_elbo_fwd")
+        ctx.family, ctx.threshold, ctx.dims = family, threshold, (B, fs, Ld)
+        ctx.save_for_backward(recon, y, mean, logvar, scale, shape, state)
+        return state[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        recon, y, mean, logvar, scale, shape, state = ctx.saved_tensors
+        B, fs, Ld = ctx.dims
+        fam = ctx.family
+        dev = recon.device
+        gout = gout.contiguous().reshape(1)
+        drecon = torch.empty_like(recon)
+        new = lambda: torch.empty(B, Ld, device=dev, dtype=torch.float32)
+        dmean = dlogvar = dscale = dshape = dpi = None
+        if fam != L.GPD:
+            dmean, dlogvar = new(), new()
+        if fam != L.GAUSSIAN:
+            dscale, dshape = new(), new()
+        if fam == L.MIXTURE:
+            dpi = torch.empty(2, device=dev, dtype=torch.float32)
+        L.check(lib.vts_elbo_bwd(fam, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape),
+                                 L.ptr(state), L.ptr(gout), ctx.threshold, L.ptr(drecon), L.ptr(dmean),
+                                 L.ptr(dlogvar), L.ptr(dscale), L.ptr(dshape), L.ptr(dpi), B, fs, Ld, L.stream()),
+                "vts_elbo_bwd")
+        return None, drecon, None, dmean, dlogvar, dscale, dshape, dpi, None, None
+
+
+def gaussian_elbo(pred, y, mean, logvar, beta: float = 0.001) -> torch.Tensor:
+    """mse(pred, y) + beta * mean_B(-0.5 * sum_L(1 + logvar - mean^2 - exp(logvar)))."""
+    return _Elbo.apply(L.GAUSSIAN, pred, y, mean, logvar, None, None, None, 0.0, beta)
+
+
+def gpd_elbo(recon, y, scale, shape, threshold: float = 95.0, beta: float = 0.001) -> torch.Tensor:
+    """mse(recon, y) + beta * mean(log(scale) + log(1 + shape * threshold / scale))."""
+    return _Elbo.apply(L.GPD, recon, y, None, None, scale, shape, None, float(threshold), beta)
+
+
+def mixture_elbo(recon, y, mean, logvar, scale, shape, pi_params, threshold: float = 95.0,
+                 beta: float = 0.001) -> torch.Tensor:
+    """mse + pi_g * (mse over |y| <= threshold + beta * KL_gaussian) + pi_p * (mse + beta * KL_gpd),
+    (pi_g, pi_p) = softmax(pi_params).  NaN when no |y| <= threshold, as in the reference."""
+    return _Elbo.apply(L.MIXTURE, recon, y, mean, logvar, scale, shape, pi_params, float(threshold), beta)

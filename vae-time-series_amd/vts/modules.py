@@ -1,0 +1,238 @@
+"""Drop-in nn.Modules: ``LSTM`` (nn.LSTM-compatible parameters and return value) and the three
+VAE families with the reference's attribute names, so a reference ``state_dict`` loads as is.
+
+Reference classes mirrored (vae-models/): gaussian-lstm-DE.py:13-70, gpd-lstm-DE.py:15-71,
+mixture-vae-DE.py:42-130.  Every forward takes an optional ``noise`` dict so the random draws
+(eps, u, choice, dropout keep masks) can be fed in for parity; otherwise they are drawn on the
+device in the reference's order.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as F
+
+Noise = Optional[Dict[str, torch.Tensor]]
+
+
+class LSTM(nn.Module):
+    """nn.LSTM(input_size, hidden_size, num_layers, batch_first=True) on the vts kernels.
+
+    Parameters are named and shaped like nn.LSTM's (weight_ih_l{k} [4H,in], weight_hh_l{k}
+    [4H,H], bias_ih_l{k}, bias_hh_l{k} [4H]; gate order i,f,g,o; init U(-1/sqrt(H), 1/sqrt(H))).
+    ``forward(x) -> (output, (h_n, c_n))``.  Initial state is zero; bidirectional, proj_size,
+    inter-layer dropout, packed sequences and seq-first layout are not supported."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, bias: bool = True,
+                 batch_first: bool = True, dropout: float = 0.0, bidirectional: bool = False,
+                 proj_size: int = 0):
+        super().__init__()
+        if not batch_first:
+            raise NotImplementedError("vts.LSTM supports batch_first=True only")
+        if not bias or dropout != 0.0 or bidirectional or proj_size != 0:
+            raise NotImplementedError("vts.LSTM: bias=False, dropout, bidirectional and proj_size are not supported")
+        if hidden_size not in (16, 32, 64, 128, 256):
+            raise NotImplementedError("vts.LSTM: hidden_size must be one of 16, 32, 64, 128, 256")
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.batch_first = True
+        bound = 1.0 / math.sqrt(hidden_size)
+        for k in range(num_layers):
+            cin = input_size if k == 0 else hidden_size
+            for name, shape in ((f"weight_ih_l{k}", (4 * hidden_size, cin)),
+                                (f"weight_hh_l{k}", (4 * hidden_size, hidden_size)),
+                                (f"bias_ih_l{k}", (4 * hidden_size,)), (f"bias_hh_l{k}", (4 * hidden_size,))):
+                self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-bound, bound)))
+
+    def flat_weights(self):
+        out = []
+        for k in range(self.num_layers):
+            out += [getattr(self, f"weight_ih_l{k}"), getattr(self, f"weight_hh_l{k}"),
+                    getattr(self, f"bias_ih_l{k}"), getattr(self, f"bias_hh_l{k}")]
+        return out
+
+    def forward(self, x: torch.Tensor, hx=None):
+        if hx is not None:
+            raise NotImplementedError("vts.LSTM: a non-zero initial state is not supported")
+        if isinstance(x, nn.utils.rnn.PackedSequence):
+            raise NotImplementedError("vts.LSTM: packed sequences are not supported")
+        if x.dim() != 3 or x.shape[2] != self.input_size:
+            raise ValueError(f"vts.LSTM: expected input [B, T, {self.input_size}], got {tuple(x.shape)}")
+        out, h_n, c_n = F.lstm(x, self.flat_weights(), self.num_layers)
+        return out, (h_n, c_n)
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose forward runs the vts GEMM with an optional fused activation."""
+
+    def forward(self, x: torch.Tensor, act: int = L.ACT_NONE, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return F.linear(x, self.weight, self.bias, act, keep)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+def _keep_mask(noise: Noise, key: str, training: bool, shape, device) -> Optional[torch.Tensor]:
+    """Dropout keep mask: fed in, drawn (train mode) or None (eval mode = no dropout)."""
+    if noise is not None and key in noise:
+        return noise[key]
+    if not training:
+        return None
+    return (torch.rand(shape, device=device) >= F.DROP_P).float()
+
+
+# ------------------------------------------------------------------------------ Gaussian VAE
+class GaussianEncoder(nn.Module):
+    def __init__(self, input_dim, lstm_output_dim, latent_dim):
+        super().__init__()
+        self.lstm = LSTM(input_dim, lstm_output_dim, batch_first=True)
+        self.mean_layer = Linear(lstm_output_dim, latent_dim)
+        self.logvar_layer = Linear(lstm_output_dim, latent_dim)
+
+    def forward(self, x):
+        _, (h_n, _) = self.lstm(x)
+        h = h_n[-1]
+        return self.mean_layer(h), self.logvar_layer(h)
+
+
+class GaussianDecoder(nn.Module):
+    def __init__(self, latent_dim, future_steps):
+        super().__init__()
+        self.dense1 = Linear(latent_dim, 500)
+        self.out = Linear(500, future_steps)
+
+    def forward(self, z):
+        return self.out(self.dense1(z, act=L.ACT_RELU))
+
+
+class GaussianVAE(nn.Module):
+    """gaussian-lstm-DE.py:48-70."""
+    kind = "gaussian"
+
+    def __init__(self, input_dim, lstm_output_dim, latent_dim, future_steps, beta=0.001):
+        super().__init__()
+        self.encoder = GaussianEncoder(input_dim, lstm_output_dim, latent_dim)
+        self.decoder = GaussianDecoder(latent_dim, future_steps)
+        self.beta = beta
+
+    def reparameterize(self, mean, logvar, eps=None):
+        return F.reparameterize_gaussian(mean, logvar, eps)
+
+    def forward(self, x, noise: Noise = None):
+        z_mean, z_log_var = self.encoder(x)
+        z = self.reparameterize(z_mean, z_log_var, None if noise is None else noise.get("eps"))
+        return self.decoder(z), z_mean, z_log_var
+
+    def loss_function(self, forecasting, y, z_mean, z_log_var):
+        return F.gaussian_elbo(forecasting, y, z_mean, z_log_var, self.beta)
+
+
+# --------------------------------------------------------------------- GPD and mixture VAEs
+class DeepEncoder(nn.Module):
+    """3-layer LSTM -> LayerNorm -> relu(fc1) -> dropout(relu(fc2)) -> heads."""
+
+    def __init__(self, input_dim, lstm_output_dim, latent_dim, gaussian_heads: bool):
+        super().__init__()
+        self.lstm = LSTM(input_dim, lstm_output_dim, num_layers=3, batch_first=True)
+        self.layer_norm = LayerNorm(lstm_output_dim)
+        self.fc1 = Linear(lstm_output_dim, 128)
+        self.fc2 = Linear(128, 64)
+        if gaussian_heads:
+            self.mean_layer_normal = Linear(64, latent_dim)
+            self.logvar_layer_normal = Linear(64, latent_dim)
+        self.scale_layer_extreme = Linear(64, latent_dim)
+        self.shape_layer_extreme = Linear(64, latent_dim)
+        self.gaussian_heads = gaussian_heads
+
+    def forward(self, x, noise: Noise = None):
+        _, (h_n, _) = self.lstm(x)
+        h = self.layer_norm(h_n[-1])
+        hidden = self.fc1(h, act=L.ACT_RELU)
+        keep = _keep_mask(noise, "enc_keep", self.training, (hidden.shape[0], 64), hidden.device)
+        hidden = self.fc2(hidden, act=L.ACT_RELU_DROPOUT, keep=keep)
+        scale = self.scale_layer_extreme(hidden, act=L.ACT_EXP)
+        shape = self.shape_layer_extreme(hidden, act=L.ACT_CLAMP_MIN)
+        if self.gaussian_heads:
+            return self.mean_layer_normal(hidden), self.logvar_layer_normal(hidden), scale, shape
+        return scale, shape
+
+
+class DeepDecoder(nn.Module):
+    def __init__(self, latent_dim, future_steps):
+        super().__init__()
+        self.fc1 = Linear(latent_dim, 128)
+        self.fc2 = Linear(128, 500)
+        self.out = Linear(500, future_steps)
+
+    def forward(self, z, noise: Noise = None):
+        z = self.fc1(z, act=L.ACT_RELU)
+        keep = _keep_mask(noise, "dec_keep", self.training, (z.shape[0], 500), z.device)
+        z = self.fc2(z, act=L.ACT_RELU_DROPOUT, keep=keep)
+        return self.out(z)
+
+
+class GPDVAE(nn.Module):
+    """gpd-lstm-DE.py:50-71.  ``threshold`` replaces the script's module global (:84)."""
+    kind = "gpd"
+
+    def __init__(self, input_dim, lstm_output_dim, latent_dim, future_steps, beta=0.001, threshold=95.0):
+        super().__init__()
+        self.encoder = DeepEncoder(input_dim, lstm_output_dim, latent_dim, gaussian_heads=False)
+        self.decoder = DeepDecoder(latent_dim, future_steps)
+        self.beta, self.threshold = beta, threshold
+
+    def reparameterize(self, scale, shape, u=None):
+        return F.reparameterize_gpd(scale, shape, scale.size(), u)
+
+    def forward(self, x, noise: Noise = None):
+        # draw order of the reference: encoder dropout, u, decoder dropout
+        scale, shape = self.encoder(x, noise)
+        z = self.reparameterize(scale, shape, None if noise is None else noise.get("u"))
+        return self.decoder(z, noise), scale, shape
+
+    def loss_function(self, reconstructed, y, scale, shape, threshold=None):
+        thr = self.threshold if threshold is None else threshold
+        return F.gpd_elbo(reconstructed, y, scale, shape, thr, self.beta)
+
+
+class MixtureVAE(nn.Module):
+    """mixture-vae-DE.py:86-130.  ``threshold`` replaces the script's module global (:143)."""
+    kind = "mixture"
+
+    def __init__(self, input_dim, lstm_output_dim, latent_dim, future_steps, beta=0.001, threshold=95.0):
+        super().__init__()
+        self.encoder = DeepEncoder(input_dim, lstm_output_dim, latent_dim, gaussian_heads=True)
+        self.decoder = DeepDecoder(latent_dim, future_steps)
+        self.beta, self.threshold = beta, threshold
+        self.pi_params = nn.Parameter(torch.tensor([3.0, 0.01]))
+
+    def reparameterize(self, mean, logvar, scale, shape, choice=None, eps=None, u=None):
+        return F.reparameterize_mixture(mean, logvar, scale, shape, self.pi_params, choice, eps, u)
+
+    def forward(self, x, noise: Noise = None):
+        # draw order of the reference: encoder dropout, choice, eps, u, decoder dropout
+        mean, logvar, scale, shape = self.encoder(x, noise)
+        n = noise or {}
+        z = self.reparameterize(mean, logvar, scale, shape, n.get("choice"), n.get("eps"), n.get("u"))
+        return self.decoder(z, noise), mean, logvar, scale, shape
+
+    def loss_function(self, reconstructed, y, mean, logvar, scale, shape, threshold=None):
+        thr = self.threshold if threshold is None else threshold
+        return F.mixture_elbo(reconstructed, y, mean, logvar, scale, shape, self.pi_params, thr, self.beta)
+
+
+def build_model(kind: str, input_dim: int, lstm_output_dim: int, latent_dim: int, future_steps: int = 1,
+                beta: float = 0.001, threshold: float = 95.0) -> nn.Module:
+    if kind == "gaussian":
+        return GaussianVAE(input_dim, lstm_output_dim, latent_dim, future_steps, beta)
+    if kind == "gpd":
+        return GPDVAE(input_dim, lstm_output_dim, latent_dim, future_steps, beta, threshold)
+    if kind == "mixture":
+        return MixtureVAE(input_dim, lstm_output_dim, latent_dim, future_steps, beta, threshold)
+    raise ValueError(f"unknown model kind {kind!r}")

@@ -1,0 +1,97 @@
+"""Train-step driver: flat parameter/gradient storage, the fused Adam kernel and
+``train_step`` (zero_grad -> forward -> loss -> backward -> Adam.step), the counterpart of the
+loop bodies at gaussian-lstm-DE.py:149-156, gpd-lstm-DE.py:99-105, mixture-vae-DE.py:158-164.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+class FlatParameters:
+    """Re-homes every parameter of ``module`` into one contiguous fp32 buffer (and its gradient
+    into a second one), so the optimizer is a single kernel launch and the data-parallel
+    all-reduce moves a few large buckets.  Parameter order = ``module.named_parameters()``.
+    Offsets are rounded up to 4 floats so every view is 16-byte aligned."""
+
+    def __init__(self, module: nn.Module):
+        self.names: List[str] = []
+        self.params: List[nn.Parameter] = []
+        self.offsets: List[int] = []
+        off = 0
+        for name, p in module.named_parameters():
+            if p.dtype != torch.float32:
+                raise TypeError(f"{name}: vts trains float32 parameters only")
+            self.names.append(name)
+            self.params.append(p)
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        device = self.params[0].device
+        self.data = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            view = self.data[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self) -> None:
+        """Gradients stay views of the flat buffer; autograd accumulates into them in place."""
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def span(self, first: int, last: int):
+        """[start, end) float offsets covering parameters first..last (inclusive)."""
+        end = self.offsets[last] + (self.params[last].numel() + 3) // 4 * 4
+        return self.offsets[first], end
+
+
+class Adam:
+    """torch.optim.Adam(params, lr) with default betas/eps, no weight decay, as one HIP kernel
+    over a FlatParameters buffer.  ``grad_scale`` is applied to the gradient first."""
+
+    def __init__(self, flat: FlatParameters, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.flat, self.lr, self.betas, self.eps = flat, lr, betas, eps
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.step_count = 0
+
+    def zero_grad(self) -> None:
+        self.flat.zero_grad()
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        lib = L.load()
+        self.step_count += 1
+        f = self.flat
+        L.check(lib.vts_adam_step(L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                  f.numel, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                  grad_scale, L.stream()), "vts_adam_step")
+
+
+def forward_loss(model: nn.Module, x: torch.Tensor, y: torch.Tensor,
+                 noise: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    outs = model(x, noise)
+    return model.loss_function(outs[0], y, *outs[1:])
+
+
+def train_step(model: nn.Module, opt: Optional[Adam], x: torch.Tensor, y: torch.Tensor,
+               noise: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """One optimisation step; returns the loss as a device scalar (no host sync).  With
+    ``opt=None`` only forward + backward run (gradients are left in ``p.grad``)."""
+    if opt is not None:
+        opt.zero_grad()
+    else:
+        for p in model.parameters():
+            p.grad = None
+    loss = forward_loss(model, x, y, noise)
+    loss.backward()
+    if opt is not None:
+        opt.step()
+    return loss.detach()
