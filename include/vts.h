@@ -82,6 +82,34 @@ int vts_lstm_layer_bwd(const float* x, const float* hseq, const float* w_ih, con
                        size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H,
                        int dtype_mode, vts_stream_t stream);
 
+/* The stages of a layer as separate entry points (same buffers and conventions as above), for
+ * callers that schedule or time them individually.  layer_fwd = inproj_fwd + recurrent_fwd;
+ * layer_bwd = recurrent_bwd + dgrad + wgrad(x, tshift 0) + wgrad(hseq, tshift -1). */
+size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H);
+size_t vts_lstm_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t F, int64_t H);
+/* gates <- x . w_ih^T + b_ih + b_hh for every step at once (one GEMM over B*T rows) */
+int vts_lstm_inproj_fwd(const float* x, const float* w_ih, const float* b_ih, const float* b_hh,
+                        float* gates, int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode,
+                        vts_stream_t stream);
+/* persistent recurrence: gates (pre-activations in, activations out), cells, hseq, h_last, c_last */
+int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_last, float* c_last,
+                           const float* w_hh, void* workspace, size_t workspace_bytes, int64_t B,
+                           int64_t T, int64_t H, int dtype_mode, vts_stream_t stream);
+/* reverse recurrence: gates (activations in, pre-activation gradients out), bias gradients */
+int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq_t16,
+                           const float* dh_last, const float* dc_last, const float* w_hh,
+                           float* db_ih, float* db_hh, int accumulate, void* workspace,
+                           size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
+                           vts_stream_t stream);
+/* dx_t16 <- dgates . w_ih (gradient w.r.t. the layer input sequence; Cin % 16 == 0) */
+int vts_lstm_dgrad(const float* dgates, const float* w_ih, float* dx_t16, int64_t B, int64_t T,
+                   int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream);
+/* dw[4H,F] (+)= sum over (b,t) of dgates[b,t,:]^T x[b,t+tshift,:F]; tshift 0 for w_ih (x = layer
+ * input), -1 for w_hh (x = hseq; step -1 is the zero initial state) */
+int vts_lstm_wgrad(const float* dgates, const float* x, int tshift, float* dw, int accumulate,
+                   void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t F, int64_t H,
+                   int dtype_mode, vts_stream_t stream);
+
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,
                        vts_stream_t stream);

@@ -188,8 +188,10 @@ __global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, i
     c_norm = p0 * 2.f / s[2];
     c_klg = p0 * beta * -0.5f / (float)B;
     c_klp = p1 * beta / (float)nlat;
-    dpi0 = p0 * p1 * (Ag - Ap);
-    dpi1 = -dpi0;
+    // softmax backward in the form autograd evaluates it: p_i * (g_i - sum_j p_j g_j)
+    const float sg = Ag * p0 + Ap * p1;
+    dpi0 = p0 * (Ag - sg);
+    dpi1 = p1 * (Ap - sg);
   }
   out[0] = loss; out[1] = c_all; out[2] = c_norm; out[3] = c_klg; out[4] = c_klp;
   out[5] = 0.f; out[6] = 0.f; out[7] = 0.f; out[8] = dpi0; out[9] = dpi1;

@@ -94,32 +94,19 @@ size_t vts_lstm_gates_bytes(int64_t B, int64_t T, int64_t H) { return (size_t)pa
 size_t vts_lstm_cells_bytes(int64_t B, int64_t T, int64_t H) { return (size_t)pad16(B) * T * H * sizeof(float); }
 size_t vts_lstm_seqgrad_bytes(int64_t B, int64_t T, int64_t F) { return (size_t)pad16(B) * T * F * sizeof(float); }
 
-struct LstmWs {
-  float* wpack;   // 4H*H
-  float* dbpart;  // nbt*4H
-  float* slabs;   // wgrad split-K partials
-  int ks_ih, ks_hh;
-  size_t total;
-};
-
-static LstmWs lstm_ws_layout(void* base, int64_t B, int64_t T, int64_t Cin, int64_t H) {
-  LstmWs w{};
-  const long Bp = pad16(B);
-  char* p = reinterpret_cast<char*>(base);
-  size_t off = 0;
-  w.wpack = reinterpret_cast<float*>(p + off); off += round256((size_t)4 * H * H * sizeof(float));
-  w.dbpart = reinterpret_cast<float*>(p + off); off += round256((size_t)(Bp / 16) * 4 * H * sizeof(float));
-  w.ks_ih = vts_gemm_pick_ksplit((int)(4 * H), (int)Cin, Bp * T);
-  w.ks_hh = vts_gemm_pick_ksplit((int)(4 * H), (int)H, Bp * T);
-  const size_t s1 = vts_gemm_slab_bytes((int)(4 * H), (int)Cin, w.ks_ih);
-  const size_t s2 = vts_gemm_slab_bytes((int)(4 * H), (int)H, w.ks_hh);
-  w.slabs = reinterpret_cast<float*>(p + off); off += round256(s1 > s2 ? s1 : s2);
-  w.total = off;
-  return w;
+// workspace of the recurrent kernels: packed W_hh image + per-batch-tile bias partials
+static size_t rec_ws_pack_bytes(int64_t H) { return round256((size_t)4 * H * H * sizeof(float)); }
+size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
+  (void)T;
+  return rec_ws_pack_bytes(H) + round256((size_t)(pad16(B) / 16) * 4 * H * sizeof(float));
 }
-
+size_t vts_lstm_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t F, int64_t H) {
+  const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T);
+  return round256(vts_gemm_slab_bytes((int)(4 * H), (int)F, ks)) + 256;
+}
 size_t vts_lstm_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H) {
-  return lstm_ws_layout(nullptr, B, T, Cin, H).total;
+  const size_t w1 = vts_lstm_wgrad_workspace_bytes(B, T, Cin, H), w2 = vts_lstm_wgrad_workspace_bytes(B, T, H, H);
+  return vts_lstm_recurrent_workspace_bytes(B, T, H) + (w1 > w2 ? w1 : w2);
 }
 
 static int lstm_check(int64_t B, int64_t T, int64_t Cin, int64_t H) {
@@ -133,23 +120,88 @@ static int lstm_check(int64_t B, int64_t T, int64_t Cin, int64_t H) {
   return VTS_OK;
 }
 
+int vts_lstm_inproj_fwd(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* gates,
+                        int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, Cin, H));
+  VTS_REQUIRE(x && w_ih && gates, "lstm_inproj_fwd: null pointer");
+  VTS_REQUIRE(vts_aligned16(gates), "lstm_inproj_fwd: gates must be 16-byte aligned");
+  return vts_gemm_inproj(x, w_ih, b_ih, b_hh, gates, (int)B, (int)T, (int)Cin, (int)(4 * H),
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_last, float* c_last, const float* w_hh,
+                           void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
+                           vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, 1, H));
+  VTS_REQUIRE(gates && cells && hseq && w_hh && workspace, "lstm_recurrent_fwd: null pointer");
+  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(hseq) && vts_aligned16(workspace) &&
+                  (!h_last || vts_aligned16(h_last)),
+              "lstm_recurrent_fwd: gates, cells, hseq, h_last and workspace must be 16-byte aligned");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_recurrent_workspace_bytes(B, T, H),
+              "lstm_recurrent_fwd: workspace %zu B too small", workspace_bytes);
+  return vts_lstm_rec_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), (int)B,
+                          (int)T, (int)H, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
+                           const float* dc_last, const float* w_hh, float* db_ih, float* db_hh, int accumulate,
+                           void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
+                           vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, 1, H));
+  VTS_REQUIRE(gates && cells && w_hh && workspace, "lstm_recurrent_bwd: null pointer");
+  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(workspace) &&
+                  (!dh_seq_t16 || vts_aligned16(dh_seq_t16)),
+              "lstm_recurrent_bwd: tile16 buffers and workspace must be 16-byte aligned");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_recurrent_workspace_bytes(B, T, H),
+              "lstm_recurrent_bwd: workspace %zu B too small", workspace_bytes);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* wpack = reinterpret_cast<float*>(workspace);
+  float* dbpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + rec_ws_pack_bytes(H));
+  const int nbt = (int)(pad16(B) / 16);
+  VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
+  if (db_ih) VTS_RC(vts_colsum_partials(dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));
+  if (db_hh) VTS_RC(vts_colsum_partials(dbpart, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
+  return VTS_OK;
+}
+
+int vts_lstm_dgrad(const float* dgates, const float* w_ih, float* dx_t16, int64_t B, int64_t T, int64_t Cin,
+                   int64_t H, int dtype_mode, vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, Cin, H));
+  VTS_REQUIRE(dgates && w_ih && dx_t16, "lstm_dgrad: null pointer");
+  VTS_REQUIRE((Cin % 16) == 0, "lstm_dgrad: needs Cin %% 16 == 0 (got %ld)", (long)Cin);
+  VTS_REQUIRE(vts_aligned16(dgates) && vts_aligned16(dx_t16) && vts_aligned16(w_ih), "lstm_dgrad: 16-byte alignment");
+  return vts_gemm_dgrad_t16(dgates, w_ih, dx_t16, (int)B, (int)T, (int)Cin, (int)(4 * H), 0,
+                            reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_lstm_wgrad(const float* dgates, const float* x, int tshift, float* dw, int accumulate, void* workspace,
+                   size_t workspace_bytes, int64_t B, int64_t T, int64_t F, int64_t H, int dtype_mode,
+                   vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, F, H));
+  VTS_REQUIRE(dgates && x && dw && workspace, "lstm_wgrad: null pointer");
+  VTS_REQUIRE(tshift == 0 || tshift == -1, "lstm_wgrad: tshift must be 0 (input weights) or -1 (recurrent weights)");
+  VTS_REQUIRE(vts_aligned16(dgates) && vts_aligned16(workspace), "lstm_wgrad: 16-byte alignment");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_wgrad_workspace_bytes(B, T, F, H), "lstm_wgrad: workspace %zu B too small",
+              workspace_bytes);
+  const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T);
+  return vts_gemm_wgrad_t16(dgates, x, dw, reinterpret_cast<float*>(workspace), ks, (int)B, (int)T, (int)F, F,
+                            (int)(4 * H), tshift, accumulate, reinterpret_cast<hipStream_t>(stream));
+}
+
 int vts_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                        float* gates, float* cells, float* hseq, float* h_last, float* c_last, void* workspace,
                        size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode,
                        vts_stream_t stream) {
-  VTS_MODE_CHECK(dtype_mode);
-  VTS_RC(lstm_check(B, T, Cin, H));
-  VTS_REQUIRE(x && w_ih && w_hh && gates && cells && hseq && workspace, "lstm_layer_fwd: null pointer");
-  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(hseq) && vts_aligned16(workspace) &&
-                  vts_aligned16(w_hh),
-              "lstm_layer_fwd: gates, cells, hseq, w_hh and workspace must be 16-byte aligned");
-  const LstmWs ws = lstm_ws_layout(workspace, B, T, Cin, H);
-  VTS_REQUIRE(workspace_bytes >= ws.total, "lstm_layer_fwd: workspace %zu B < required %zu B", workspace_bytes,
-              ws.total);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  VTS_RC(vts_gemm_inproj(x, w_ih, b_ih, b_hh, gates, (int)B, (int)T, (int)Cin, (int)(4 * H), st));
-  VTS_RC(vts_lstm_rec_fwd(gates, cells, hseq, h_last, c_last, w_hh, ws.wpack, (int)B, (int)T, (int)H, st));
-  return VTS_OK;
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_workspace_bytes(B, T, Cin, H), "lstm_layer_fwd: workspace %zu B too small",
+              workspace_bytes);
+  VTS_RC(vts_lstm_inproj_fwd(x, w_ih, b_ih, b_hh, gates, B, T, Cin, H, dtype_mode, stream));
+  return vts_lstm_recurrent_fwd(gates, cells, hseq, h_last, c_last, w_hh, workspace, workspace_bytes, B, T, H,
+                                dtype_mode, stream);
 }
 
 int vts_lstm_layer_bwd(const float* x, const float* hseq, const float* w_ih, const float* w_hh, float* gates,
@@ -157,29 +209,17 @@ int vts_lstm_layer_bwd(const float* x, const float* hseq, const float* w_ih, con
                        float* dx_t16, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int accumulate,
                        void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H,
                        int dtype_mode, vts_stream_t stream) {
-  VTS_MODE_CHECK(dtype_mode);
-  VTS_RC(lstm_check(B, T, Cin, H));
-  VTS_REQUIRE(x && hseq && w_ih && w_hh && gates && cells && workspace, "lstm_layer_bwd: null pointer");
-  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(workspace) &&
-                  (!dh_seq_t16 || vts_aligned16(dh_seq_t16)) && (!dx_t16 || vts_aligned16(dx_t16)),
-              "lstm_layer_bwd: tile16 buffers and workspace must be 16-byte aligned");
-  VTS_REQUIRE(dx_t16 == nullptr || (Cin % 16) == 0, "lstm_layer_bwd: dx needs Cin %% 16 == 0 (got %ld)", (long)Cin);
-  const LstmWs ws = lstm_ws_layout(workspace, B, T, Cin, H);
-  VTS_REQUIRE(workspace_bytes >= ws.total, "lstm_layer_bwd: workspace %zu B < required %zu B", workspace_bytes,
-              ws.total);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int nbt = (int)(pad16(B) / 16);
-  VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, ws.dbpart, w_hh, ws.wpack, (int)B, (int)T,
-                          (int)H, st));
-  if (db_ih) VTS_RC(vts_colsum_partials(ws.dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));
-  if (db_hh) VTS_RC(vts_colsum_partials(ws.dbpart, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
-  if (dx_t16) VTS_RC(vts_gemm_dgrad_t16(gates, w_ih, dx_t16, (int)B, (int)T, (int)Cin, (int)(4 * H), 0, st));
-  if (dw_ih)
-    VTS_RC(vts_gemm_wgrad_t16(gates, x, dw_ih, ws.slabs, ws.ks_ih, (int)B, (int)T, (int)Cin, Cin, (int)(4 * H), 0,
-                              accumulate, st));
-  if (dw_hh)
-    VTS_RC(vts_gemm_wgrad_t16(gates, hseq, dw_hh, ws.slabs, ws.ks_hh, (int)B, (int)T, (int)H, H, (int)(4 * H), -1,
-                              accumulate, st));
+  VTS_REQUIRE(x && hseq && workspace, "lstm_layer_bwd: null pointer");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_workspace_bytes(B, T, Cin, H), "lstm_layer_bwd: workspace %zu B too small",
+              workspace_bytes);
+  const size_t rec_bytes = vts_lstm_recurrent_workspace_bytes(B, T, H);
+  void* wg_ws = reinterpret_cast<char*>(workspace) + rec_bytes;
+  const size_t wg_bytes = workspace_bytes - rec_bytes;
+  VTS_RC(vts_lstm_recurrent_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, w_hh, db_ih, db_hh, accumulate, workspace,
+                                workspace_bytes, B, T, H, dtype_mode, stream));
+  if (dx_t16) VTS_RC(vts_lstm_dgrad(gates, w_ih, dx_t16, B, T, Cin, H, dtype_mode, stream));
+  if (dw_ih) VTS_RC(vts_lstm_wgrad(gates, x, 0, dw_ih, accumulate, wg_ws, wg_bytes, B, T, Cin, H, dtype_mode, stream));
+  if (dw_hh) VTS_RC(vts_lstm_wgrad(gates, hseq, -1, dw_hh, accumulate, wg_ws, wg_bytes, B, T, H, H, dtype_mode, stream));
   return VTS_OK;
 }
 

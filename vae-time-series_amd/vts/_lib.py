@@ -31,6 +31,13 @@ SIGNATURES = {
     "vts_lstm_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "vts_lstm_layer_fwd": (_int, [_ptr] * 10 + [_ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_layer_bwd": (_int, [_ptr] * 14 + [_int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_recurrent_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_lstm_wgrad_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "vts_lstm_inproj_fwd": (_int, [_ptr] * 5 + [_i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_recurrent_fwd": (_int, [_ptr] * 6 + [_ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_recurrent_bwd": (_int, [_ptr] * 8 + [_int, _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_dgrad": (_int, [_ptr] * 3 + [_i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_wgrad": (_int, [_ptr, _ptr, _int, _ptr, _int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
     "vts_tile16_convert": (_int, [_ptr, _ptr, _i64, _i64, _i64, _int, _ptr]),
     "vts_linear_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _f32, _ptr, _int, _ptr]),
     "vts_linear_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -100,3 +107,38 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 def wptr(t: torch.Tensor):
     return C.c_void_p(t.data_ptr())
+
+
+class KernelTimer:
+    """Brackets selected C-ABI calls with HIP events on torch's current stream (the stream the
+    kernels are enqueued on) and accumulates device time per call name.  Used by bench.py to
+    measure the dominant kernels inside the timed region; off by default."""
+
+    def __init__(self):
+        self.records = []   # (name, start_event, end_event)
+        self.enabled = False
+
+    def call(self, name, fn, *args):
+        if not self.enabled:
+            return fn(*args)
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        rc = fn(*args)
+        end.record()
+        self.records.append((name, start, end))
+        return rc
+
+    def summary(self):
+        """name -> (launches, total_ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, s, e in self.records:
+            n, tot = out.get(name, (0, 0.0))
+            out[name] = (n + 1, tot + s.elapsed_time(e))
+        return out
+
+    def reset(self):
+        self.records = []
+
+
+timer = KernelTimer()

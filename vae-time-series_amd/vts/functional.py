@@ -43,19 +43,20 @@ class _LSTMStack(torch.autograd.Function):
             gates = L.workspace(lib.vts_lstm_gates_bytes(B, T, H), dev)
             cells = L.workspace(lib.vts_lstm_cells_bytes(B, T, H), dev)
             hseq = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-            ws_bytes = lib.vts_lstm_workspace_bytes(B, T, cin, H)
+            ws_bytes = lib.vts_lstm_recurrent_workspace_bytes(B, T, H)
             ws = L.workspace(ws_bytes, dev)
-            L.check(lib.vts_lstm_layer_fwd(L.ptr(inp), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh),
-                                           L.wptr(gates), L.wptr(cells), L.ptr(hseq), L.ptr(h_n[k]), L.ptr(c_n[k]),
-                                           L.wptr(ws), ws_bytes, B, T, cin, H, _MODE, L.stream()),
-                    "vts_lstm_layer_fwd")
+            st = L.stream()
+            L.check(L.timer.call("lstm_inproj_fwd", lib.vts_lstm_inproj_fwd, L.ptr(inp), L.ptr(w_ih), L.ptr(b_ih),
+                                 L.ptr(b_hh), L.wptr(gates), B, T, cin, H, _MODE, st), "vts_lstm_inproj_fwd")
+            L.check(L.timer.call("lstm_recurrent_fwd", lib.vts_lstm_recurrent_fwd, L.wptr(gates), L.wptr(cells),
+                                 L.ptr(hseq), L.ptr(h_n[k]), L.ptr(c_n[k]), L.ptr(w_hh), L.wptr(ws), ws_bytes,
+                                 B, T, H, _MODE, st), "vts_lstm_recurrent_fwd")
             saved += [inp, gates, cells, hseq]
             inp = hseq
         ctx.num_layers = num_layers
         ctx.dims = (B, T, C0, H)
         ctx.save_for_backward(*saved, *weights)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable()
         return inp, h_n, c_n
 
     @staticmethod
@@ -86,14 +87,23 @@ class _LSTMStack(torch.autograd.Function):
             db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
             dh_last = _c(g_hn[k]) if g_hn is not None else None
             dc_last = _c(g_cn[k]) if g_cn is not None else None
-            ws_bytes = lib.vts_lstm_workspace_bytes(B, T, cin, H)
+            st = L.stream()
+            ws_bytes = lib.vts_lstm_recurrent_workspace_bytes(B, T, H)
             ws = L.workspace(ws_bytes, dev)
-            L.check(lib.vts_lstm_layer_bwd(L.ptr(inp), L.ptr(hseq), L.ptr(w_ih), L.ptr(w_hh), L.wptr(gates),
-                                           L.wptr(cells), None if dh_seq is None else L.wptr(dh_seq),
-                                           L.ptr(dh_last), L.ptr(dc_last), None if dx is None else L.wptr(dx),
-                                           L.ptr(dw_ih), L.ptr(dw_hh), L.ptr(db_ih), L.ptr(db_hh), 0,
-                                           L.wptr(ws), ws_bytes, B, T, cin, H, _MODE, L.stream()),
-                    "vts_lstm_layer_bwd")
+            L.check(L.timer.call("lstm_recurrent_bwd", lib.vts_lstm_recurrent_bwd, L.wptr(gates), L.wptr(cells),
+                                 None if dh_seq is None else L.wptr(dh_seq), L.ptr(dh_last), L.ptr(dc_last),
+                                 L.ptr(w_hh), L.ptr(db_ih), L.ptr(db_hh), 0, L.wptr(ws), ws_bytes, B, T, H, _MODE,
+                                 st), "vts_lstm_recurrent_bwd")
+            if dx is not None:
+                L.check(L.timer.call("lstm_dgrad", lib.vts_lstm_dgrad, L.wptr(gates), L.ptr(w_ih), L.wptr(dx),
+                                     B, T, cin, H, _MODE, st), "vts_lstm_dgrad")
+            wg_bytes = max(lib.vts_lstm_wgrad_workspace_bytes(B, T, cin, H),
+                           lib.vts_lstm_wgrad_workspace_bytes(B, T, H, H))
+            wg = L.workspace(wg_bytes, dev)
+            L.check(L.timer.call("lstm_wgrad_ih", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(inp), 0, L.ptr(dw_ih), 0,
+                                 L.wptr(wg), wg_bytes, B, T, cin, H, _MODE, st), "vts_lstm_wgrad")
+            L.check(L.timer.call("lstm_wgrad_hh", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw_hh),
+                                 0, L.wptr(wg), wg_bytes, B, T, H, H, _MODE, st), "vts_lstm_wgrad")
             grads[4 * k:4 * k + 4] = [dw_ih, dw_hh, db_ih, db_hh]
             dh_seq = dx
             if k == 0:
