@@ -80,6 +80,12 @@ def test_golden_loss_and_gradients(golden, name):
             assert grads[k].abs().max().item() == 0, k
         elif k == "pi_params":
             assert pi_grad_close(grads[k], ref, ref_loss), (grads[k], ref)
+        elif "shape_layer_extreme" in k and "wellcond" not in name:
+            # default-init shape head: the rows that draw the GPD sample with a shape just above
+            # the 1e-6 clamp give d z / d shape as a difference of two ~scale/shape^2 terms; the
+            # reference's own fp32 value moves by ~1e-3 under last-bit input changes
+            # (tests/test_oracle_goldens.py::test_default_init_gpd_is_ill_conditioned)
+            assert l2_rel(grads[k], ref) < 2e-3, (k, l2_rel(grads[k], ref))
         else:
             assert l2_rel(grads[k], ref) < TOL, (k, l2_rel(grads[k], ref))
 

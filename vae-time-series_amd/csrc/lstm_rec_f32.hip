@@ -12,8 +12,6 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
 template <int H>
 struct RecCfg {
   static constexpr int JT = H / 16;                 // hidden tiles
@@ -63,16 +61,32 @@ __global__ void pack_whh_bwd_kernel(const float* __restrict__ W, float* __restri
   }
 }
 
+// ---- activations --------------------------------------------------------------------------------
+// One v_exp_f32 + one v_rcp_f32 each (about 1 ulp apiece): with one wave per SIMD every VALU
+// instruction of the cell update sits on the step's critical path, so libm-grade expf/tanhf
+// (tens of instructions) would cost a quarter of the step.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 // G     : in  gate pre-activations x.W_ih^T + b (tile16 [Bp*T, 4H]); out activated gates i,f,g,o
 // cseq  : out cell states (tile16 [Bp*T, H])
 // hseq  : out hidden states, row-major [B, T, H]
 // hlast, clast : out optional h_T, c_T row-major [B, H]
+//
+// Per step and wave: NT = 4*JPW accumulator tiles, KQ_F k-quads; the W_hh fragments of k-quad
+// kq+1 are in flight (registers w1 / w0 alternately) while the MFMAs of k-quad kq issue, and the
+// gate pre-activations of step t+1 are in flight during the whole product of step t.
 template <int H>
 __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
     float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
     float* __restrict__ clast, const float* __restrict__ Wp, int B, int T) {
   using C = RecCfg<H>;
+  constexpr int NT = C::JPW * 4;
   __shared__ __attribute__((aligned(16))) float hl[2][16 * C::LDH];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -85,51 +99,69 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
 #pragma unroll
   for (int jl = 0; jl < C::JPW; ++jl) c[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const f32x4* Wv = reinterpret_cast<const f32x4*>(Wp) + (long)wave * C::KQ_F * C::JPW * 4 * 64 + lane;
-
-  for (int t = 0; t < T; ++t) {
-    const int cur = t & 1, nxt = cur ^ 1;
-    float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
-    f32x4 acc[C::JPW][4];
+  const f32x4* Wv = reinterpret_cast<const f32x4*>(Wp) + (long)wave * C::KQ_F * NT * 64 + lane;
+  auto load_w = [&](f32x4 (&w)[NT], int kq) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) w[i] = Wv[(kq * NT + i) * 64];   // i = jl*4 + gate
+  };
+  auto load_g = [&](f32x4 (&gv)[NT], int t) {
+    const float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
 #pragma unroll
     for (int jl = 0; jl < C::JPW; ++jl)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        acc[jl][q] = *reinterpret_cast<const f32x4*>(Gt + (long)(q * C::JT + wave * C::JPW + jl) * 256);
+        gv[jl * 4 + q] = *reinterpret_cast<const f32x4*>(Gt + (long)(q * C::JT + wave * C::JPW + jl) * 256);
+  };
+
+  f32x4 gnext[NT];
+  load_g(gnext, 0);
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = gnext[i];
+    if (t + 1 < T) load_g(gnext, t + 1);
 
     if (t > 0) {
       const float* hrow = &hl[cur][r * C::LDH + 4 * g];
-#pragma unroll 2
-      for (int kq = 0; kq < C::KQ_F; ++kq) {
+      auto mma = [&](const f32x4 (&w)[NT], int kq) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(hrow + 16 * kq);
-        f32x4 w[C::JPW][4];
-#pragma unroll
-        for (int jl = 0; jl < C::JPW; ++jl)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) w[jl][q] = Wv[((kq * C::JPW + jl) * 4 + q) * 64];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int jl = 0; jl < C::JPW; ++jl)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc[jl][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[jl][q][s], acc[jl][q], 0, 0, 0);
+          for (int i = 0; i < NT; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[i][s], acc[i], 0, 0, 0);
+      };
+      f32x4 w0[NT], w1[NT];
+      load_w(w0, 0);
+      if constexpr (C::KQ_F == 1) {
+        mma(w0, 0);
+      } else {
+#pragma unroll 1
+        for (int kq = 0; kq < C::KQ_F; kq += 2) {
+          load_w(w1, kq + 1);
+          mma(w0, kq);
+          if (kq + 2 < C::KQ_F) load_w(w0, kq + 2);
+          mma(w1, kq + 1);
+        }
       }
     }
 
-    // cell update, lane-local: acc[jl][q][reg] is gate q of window row 4g+reg, hidden jt*16+r
+    // cell update, lane-local: acc[jl*4+q][reg] is gate q of window row 4g+reg, hidden jt*16+r
+    float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
 #pragma unroll
     for (int jl = 0; jl < C::JPW; ++jl) {
       const int jt = wave * C::JPW + jl;
       f32x4 gi, gf, gg, go, hv;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        gi[reg] = sigmoidf_(acc[jl][0][reg]);
-        gf[reg] = sigmoidf_(acc[jl][1][reg]);
-        gg[reg] = tanhf(acc[jl][2][reg]);
-        go[reg] = sigmoidf_(acc[jl][3][reg]);
+        gi[reg] = fast_sigmoid(acc[jl * 4 + 0][reg]);
+        gf[reg] = fast_sigmoid(acc[jl * 4 + 1][reg]);
+        gg[reg] = fast_tanh(acc[jl * 4 + 2][reg]);
+        go[reg] = fast_sigmoid(acc[jl * 4 + 3][reg]);
         c[jl][reg] = gf[reg] * c[jl][reg] + gi[reg] * gg[reg];
-        hv[reg] = go[reg] * tanhf(c[jl][reg]);
+        hv[reg] = go[reg] * fast_tanh(c[jl][reg]);
         hl[nxt][(4 * g + reg) * C::LDH + jt * 16 + r] = hv[reg];
       }
       *reinterpret_cast<f32x4*>(Gt + (long)(0 * C::JT + jt) * 256) = gi;
@@ -166,12 +198,19 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
 // dhlast  : in  optional gradient w.r.t. h_T, row-major [B, H]
 // dclast  : in  optional gradient w.r.t. c_T, row-major [B, H]
 // dbpart  : out per-batch-tile column sums of dA: [Bp/16][4H]
+//
+// Same pipelining as the forward kernel: W_hh fragments one block (KB k-quads) ahead of the
+// MFMAs, and the gates / cell states / upstream gradient of step t-1 in flight during the
+// product of step t.
 template <int H>
 __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
     float* __restrict__ G, const float* __restrict__ cseq, const float* __restrict__ dhseq,
     const float* __restrict__ dhlast, const float* __restrict__ dclast, float* __restrict__ dbpart,
     const float* __restrict__ Wp, int B, int T) {
   using C = RecCfg<H>;
+  constexpr int JPW = C::JPW;
+  constexpr int KB = 4;                        // k-quads per register block
+  constexpr int NBLK = C::KQ_B / KB;           // 4H/64 blocks: 1, 2, 4, 8, 16
   extern __shared__ __attribute__((aligned(16))) float dal[];  // [2][16 * LDA]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -180,33 +219,61 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
   const int bt = blockIdx.x;
   const int b0 = bt * 16;
 
-  f32x4 dc[C::JPW], dh[C::JPW], dbs[C::JPW][4];
+  f32x4 dc[JPW], dh[JPW];
+  float dbs[JPW][4];
 #pragma unroll
-  for (int jl = 0; jl < C::JPW; ++jl) {
+  for (int jl = 0; jl < JPW; ++jl) {
     dc[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
     dh[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dbs[jl][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) dbs[jl][q] = 0.f;
   }
-  const f32x4* Wv = reinterpret_cast<const f32x4*>(Wp) + (long)wave * C::KQ_B * C::JPW * 64 + lane;
+  const f32x4* Wv = reinterpret_cast<const f32x4*>(Wp) + (long)wave * C::KQ_B * JPW * 64 + lane;
+  auto load_w = [&](f32x4 (&w)[KB * JPW], int blk) {
+#pragma unroll
+    for (int i = 0; i < KB * JPW; ++i) w[i] = Wv[(blk * KB * JPW + i) * 64];   // i = kq_local*JPW + jl
+  };
+  // saved tensors of one step: gates [jl][4], c_t [jl], upstream dh [jl]
+  auto load_step = [&](f32x4 (&gv)[JPW * 4], f32x4 (&cv)[JPW], f32x4 (&dv)[JPW], int t) {
+    const float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      const int jt = wave * JPW + jl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        gv[jl * 4 + q] = *reinterpret_cast<const f32x4*>(Gt + (long)(q * C::JT + jt) * 256);
+      cv[jl] = *reinterpret_cast<const f32x4*>(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+      if (dhseq != nullptr)
+        dv[jl] = *reinterpret_cast<const f32x4*>(dhseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+      else
+        dv[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  f32x4 gv[JPW * 4], cv[JPW], dv[JPW];      // step t
+  f32x4 gn[JPW * 4], cn[JPW], dn[JPW];      // step t-1 (prefetched)
+  load_step(gn, cn, dn, T - 1);
 
   for (int t = T - 1; t >= 0; --t) {
     const int cur = t & 1;
     float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
     float* da_s = dal + cur * (16 * C::LDA);
 #pragma unroll
-    for (int jl = 0; jl < C::JPW; ++jl) {
-      const int jt = wave * C::JPW + jl;
-      const f32x4 gi = *reinterpret_cast<const f32x4*>(Gt + (long)(0 * C::JT + jt) * 256);
-      const f32x4 gf = *reinterpret_cast<const f32x4*>(Gt + (long)(1 * C::JT + jt) * 256);
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(Gt + (long)(2 * C::JT + jt) * 256);
-      const f32x4 go = *reinterpret_cast<const f32x4*>(Gt + (long)(3 * C::JT + jt) * 256);
-      const f32x4 ct = *reinterpret_cast<const f32x4*>(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
-      f32x4 cp = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t > 0) cp = *reinterpret_cast<const f32x4*>(cseq + ((long)(bt * T + t - 1) * C::JT + jt) * 256 + lane * 4);
-      f32x4 dht = dh[jl];
-      if (dhseq != nullptr)
-        dht += *reinterpret_cast<const f32x4*>(dhseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+    for (int i = 0; i < JPW * 4; ++i) gv[i] = gn[i];
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) { cv[jl] = cn[jl]; dv[jl] = dn[jl]; }
+    if (t > 0) load_step(gn, cn, dn, t - 1);   // cn doubles as c_{t-1} of this step
+    else {
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl) cn[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      const int jt = wave * JPW + jl;
+      const f32x4 gi = gv[jl * 4 + 0], gf = gv[jl * 4 + 1], gg = gv[jl * 4 + 2], go = gv[jl * 4 + 3];
+      const f32x4 ct = cv[jl], cp = cn[jl];
+      f32x4 dht = dh[jl] + dv[jl];
       if (t == T - 1) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -220,7 +287,7 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
       f32x4 dai, daf, dag, dao;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const float tc = tanhf(ct[reg]);
+        const float tc = fast_tanh(ct[reg]);
         const float d_o = dht[reg] * tc;
         const float dcc = dc[jl][reg] + dht[reg] * go[reg] * (1.f - tc * tc);
         const float d_i = dcc * gg[reg];
@@ -235,7 +302,10 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
         *reinterpret_cast<f32x4*>(&da_s[(4 * g + reg) * C::LDA + 4 * (jt * 16 + r)]) =
             f32x4{dai[reg], daf[reg], dag[reg], dao[reg]};
       }
-      dbs[jl][0] += dai; dbs[jl][1] += daf; dbs[jl][2] += dag; dbs[jl][3] += dao;
+      dbs[jl][0] += (dai[0] + dai[1]) + (dai[2] + dai[3]);
+      dbs[jl][1] += (daf[0] + daf[1]) + (daf[2] + daf[3]);
+      dbs[jl][2] += (dag[0] + dag[1]) + (dag[2] + dag[3]);
+      dbs[jl][3] += (dao[0] + dao[1]) + (dao[2] + dao[3]);
       *reinterpret_cast<f32x4*>(Gt + (long)(0 * C::JT + jt) * 256) = dai;
       *reinterpret_cast<f32x4*>(Gt + (long)(1 * C::JT + jt) * 256) = daf;
       *reinterpret_cast<f32x4*>(Gt + (long)(2 * C::JT + jt) * 256) = dag;
@@ -244,33 +314,45 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
     if (t == 0) break;  // dh_{-1} is not needed
     __syncthreads();
     // dh_rec[16 x H-slice] = dA[16 x 4H] . W_hh[4H x H-slice]
-    f32x4 acc[C::JPW];
+    f32x4 acc[JPW];
 #pragma unroll
-    for (int jl = 0; jl < C::JPW; ++jl) acc[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jl = 0; jl < JPW; ++jl) acc[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* arow = &da_s[r * C::LDA + 4 * g];
-#pragma unroll 4
-    for (int kq = 0; kq < C::KQ_B; ++kq) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * kq);
-      f32x4 w[C::JPW];
+    auto mma = [&](const f32x4 (&w)[KB * JPW], int blk) {
 #pragma unroll
-      for (int jl = 0; jl < C::JPW; ++jl) w[jl] = Wv[(kq * C::JPW + jl) * 64];
+      for (int kl = 0; kl < KB; ++kl) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * (blk * KB + kl));
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int jl = 0; jl < C::JPW; ++jl)
-          acc[jl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[jl][s], acc[jl], 0, 0, 0);
+          for (int jl = 0; jl < JPW; ++jl)
+            acc[jl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[kl * JPW + jl][s], acc[jl], 0, 0, 0);
+      }
+    };
+    f32x4 w0[KB * JPW], w1[KB * JPW];
+    load_w(w0, 0);
+    if constexpr (NBLK == 1) {
+      mma(w0, 0);
+    } else {
+#pragma unroll 1
+      for (int blk = 0; blk < NBLK; blk += 2) {
+        load_w(w1, blk + 1);
+        mma(w0, blk);
+        if (blk + 2 < NBLK) load_w(w0, blk + 2);
+        mma(w1, blk + 1);
+      }
     }
 #pragma unroll
-    for (int jl = 0; jl < C::JPW; ++jl) dh[jl] = acc[jl];
+    for (int jl = 0; jl < JPW; ++jl) dh[jl] = acc[jl];
   }
 
-  // bias-gradient partials: sum the 4 rows of each lane, then the 4 row groups (lanes r, r+16, r+32, r+48)
+  // bias-gradient partials: sum over the 4 row groups (lanes r, r+16, r+32, r+48)
 #pragma unroll
-  for (int jl = 0; jl < C::JPW; ++jl) {
-    const int jt = wave * C::JPW + jl;
+  for (int jl = 0; jl < JPW; ++jl) {
+    const int jt = wave * JPW + jl;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float s = dbs[jl][q][0] + dbs[jl][q][1] + dbs[jl][q][2] + dbs[jl][q][3];
+      float s = dbs[jl][q];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       if (g == 0) dbpart[(long)bt * (4 * H) + q * H + jt * 16 + r] = s;
