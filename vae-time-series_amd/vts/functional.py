@@ -17,6 +17,12 @@ DROP_P = 0.3
 _MODE = 0  # dtype_mode of the C ABI: 0 = fp32 matrix-core arithmetic
 
 
+def _need_gpu(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError("vts kernels run on a ROCm device only (no CPU fallback): got a tensor on "
+                           + str(t.device))
+
+
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.contiguous()
 
@@ -28,6 +34,7 @@ class _LSTMStack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, num_layers: int, *weights: torch.Tensor):
+        _need_gpu(x)
         lib = L.load()
         x = x.contiguous()
         B, T, C0 = x.shape
@@ -125,6 +132,7 @@ def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act: int, keep):
+        _need_gpu(x)
         lib = L.load()
         if x.dim() != 2 or x.stride(1) != 1:
             x = x.reshape(-1, x.shape[-1]).contiguous()
@@ -172,6 +180,7 @@ def linear(x, weight, bias=None, act: int = L.ACT_NONE, keep: Optional[torch.Ten
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps: float):
+        _need_gpu(x)
         lib = L.load()
         if x.dim() != 2 or x.stride(1) != 1:
             x = x.reshape(-1, x.shape[-1]).contiguous()
@@ -214,6 +223,7 @@ class _Reparam(torch.autograd.Function):
     def forward(ctx, family: int, mean, logvar, scale, shape, eps, u, choice, pi):
         lib = L.load()
         ref = mean if mean is not None else scale
+        _need_gpu(ref)
         B, Ld = ref.shape
         mean, logvar, scale, shape, eps, u, choice = [_c(t) for t in (mean, logvar, scale, shape, eps, u, choice)]
         pi_d = None if pi is None else pi.detach().contiguous()
@@ -276,6 +286,7 @@ def reparameterize_mixture(mean, logvar, scale, shape, pi_params, choice=None, e
 class _Elbo(torch.autograd.Function):
     @staticmethod
     def forward(ctx, family: int, recon, y, mean, logvar, scale, shape, pi, threshold: float, beta: float):
+        _need_gpu(recon)
         lib = L.load()
         recon, y = recon.contiguous(), y.contiguous()
         B = recon.shape[0]
