@@ -118,7 +118,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -140,7 +141,7 @@ def main():
     x, y = synth_windows(a.batch, a.T, a.C, rank, dev)
 
     def sync():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +156,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     L.timer.enabled = False
-    if world > 1:
+    if launched:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -196,7 +197,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model, a.T, a.C, a.H, a.L, a.cpu_sample)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,7 +24,16 @@ enum { A_ROW = 0, A_COL = 1, A_T16 = 2, A_T16T = 3 };
 enum { B_NK = 0, B_KN = 1 };
 enum { C_ROW = 0, C_T16 = 1 };
 
+#ifndef VTS_GEMM_WPS
+#define VTS_GEMM_WPS 3
+#endif
+#ifndef VTS_GEMM_NSUB
+#define VTS_GEMM_NSUB 1
+#endif
 constexpr int BM = 128, BN = 128, BKT = 16;
+constexpr int NSUB = VTS_GEMM_NSUB;          // 16-deep k sub-chunks staged per barrier
+constexpr int BKS = BKT * NSUB;              // k elements per main-loop iteration
+constexpr size_t GEMM_LDS_BYTES = 2ul * NSUB * 2 * BKT * 144 * sizeof(float);
 constexpr int LDS_LD = 144;  // 144 % 32 == 16: the (k, k+1) x 16-column b32 fragment reads hit 32 distinct banks
 
 struct GemmParams {
@@ -58,43 +67,37 @@ __device__ __forceinline__ long window_row(int m, int T, int Bwin, int tshift, b
   return (long)b * T + t;
 }
 
-// Load 8 consecutive floats p[0..7] with validity count nvalid (elements >= nvalid read as 0),
-// using the widest access the address allows.
+// Load 8 consecutive floats p[0..7] with validity count nvalid (elements >= nvalid read as 0).
+// Full loads are two 16-byte accesses that only need 4-byte alignment (rows of 370 floats start
+// on 8-byte boundaries): one instruction stream for every lane, no alignment branches.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void load8(const float* __restrict__ p, int nvalid, float (&v)[8]) {
   if (nvalid >= 8) {
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
-    if ((addr & 15u) == 0) {
-      const float4 x = *reinterpret_cast<const float4*>(p);
-      const float4 y = *reinterpret_cast<const float4*>(p + 4);
-      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-      return;
-    }
-    if ((addr & 7u) == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float2 x = *reinterpret_cast<const float2*>(p + 2 * i);
-        v[2 * i] = x.x; v[2 * i + 1] = x.y;
-      }
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = p[i];
+    const f32x4_u x = *reinterpret_cast<const f32x4_u*>(p);
+    const f32x4_u y = *reinterpret_cast<const f32x4_u*>(p + 4);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; v[4] = y[0]; v[5] = y[1]; v[6] = y[2]; v[7] = y[3];
     return;
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (i < nvalid) ? p[i] : 0.0f;
 }
 
+// A_ROW: the memory row of this thread's logical row does not depend on k: resolved once.
+__device__ __forceinline__ const float* a_row_base(const GemmParams& P, int m0, int tid) {
+  const int m = m0 + (tid >> 1);
+  bool valid = m < P.M;
+  long row = m;
+  if (P.a_map && valid) row = window_row(m, P.T, P.Bwin, P.a_tshift, valid);
+  return valid ? P.A + row * P.lda : nullptr;
+}
+
 template <int AK>
-__device__ __forceinline__ void load_a(const GemmParams& P, int m0, int k0, int kend, int tid, float (&v)[8]) {
+__device__ __forceinline__ void load_a(const GemmParams& P, const float* arow, int m0, int k0, int kend, int tid,
+                                       float (&v)[8]) {
   if constexpr (AK == A_ROW) {
-    const int m = m0 + (tid >> 1);
     const int k = k0 + (tid & 1) * 8;
-    bool valid = m < P.M;
-    long row = m;
-    if (P.a_map && valid) row = window_row(m, P.T, P.Bwin, P.a_tshift, valid);
-    const int nv = valid ? min(8, kend - k) : 0;
-    if (nv > 0) load8(P.A + row * P.lda + k, nv, v);
+    const int nv = (arow != nullptr) ? min(8, kend - k) : 0;
+    if (nv > 0) load8(arow + k, nv, v);
     else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = 0.f;
@@ -170,13 +173,18 @@ __device__ __forceinline__ void store_a(float* __restrict__ As, int tid, const f
   }
 }
 
+__device__ __forceinline__ const float* b_row_base(const GemmParams& P, int n0, int tid) {
+  const int n = n0 + (tid >> 1);
+  return (n < P.N) ? P.B + (long)n * P.ldb : nullptr;
+}
+
 template <int BKIND>
-__device__ __forceinline__ void load_b(const GemmParams& P, int n0, int k0, int kend, int tid, float (&v)[8]) {
+__device__ __forceinline__ void load_b(const GemmParams& P, const float* brow, int n0, int k0, int kend, int tid,
+                                       float (&v)[8]) {
   if constexpr (BKIND == B_NK) {
-    const int n = n0 + (tid >> 1);
     const int k = k0 + (tid & 1) * 8;
-    const int nv = (n < P.N) ? min(8, kend - k) : 0;
-    if (nv > 0) load8(P.B + (long)n * P.ldb + k, nv, v);
+    const int nv = (brow != nullptr) ? min(8, kend - k) : 0;
+    if (nv > 0) load8(brow + k, nv, v);
     else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = 0.f;
@@ -212,19 +220,39 @@ __device__ __forceinline__ void store_b(float* __restrict__ Bs, int tid, const f
 }
 
 template <int AK, int BKIND, int CK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams P) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][BKT * LDS_LD];  // [buf][A|B]
+__global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];   // [buf][sub][A|B][BKT * LDS_LD]
+  auto lds = [&](int buf, int sub, int op) -> float* { return lds_raw + ((buf * NSUB + sub) * 2 + op) * (BKT * LDS_LD); };
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 15, g = lane >> 4;
 
+  // Workgroup -> (m tile, n tile, k slice).  Workgroups whose ids are equal mod 8 share an XCD
+  // (and its L2): all tiles that read the same operand panel - the n tiles of one m tile, or
+  // every tile of one k slice - are given ids equal mod 8 and adjacent in time, so the panel is
+  // fetched into one L2 once instead of into all eight.
   const int tiles_n = (P.N + BN - 1) / BN;
-  const int tile = blockIdx.x;
+  const int tiles_m = (P.M + BM - 1) / BM;
+  int tile, zslice;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (P.ksplit > 1) {
+      const int per = tiles_m * tiles_n;
+      zslice = (j / per) * 8 + xcd;
+      tile = j % per;
+      if (zslice >= P.ksplit) return;
+    } else {
+      const int mt = (j / tiles_n) * 8 + xcd;
+      if (mt >= tiles_m) return;
+      tile = mt * tiles_n + j % tiles_n;
+      zslice = 0;
+    }
+  }
   const int m0 = (tile / tiles_n) * BM;
   const int n0 = (tile % tiles_n) * BN;
-  const int kbeg = blockIdx.z * P.kchunk;
+  const int kbeg = zslice * P.kchunk;
   const int kend = min(P.K, kbeg + P.kchunk);
 
   f32x4 acc[4][4];
@@ -233,40 +261,59 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams P) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float va[8], vb[8];
-  const int nk = (kend - kbeg + BKT - 1) / BKT;
+  float va[NSUB][8], vb[NSUB][8];
+  const float* arow = nullptr;
+  const float* brow = nullptr;
+  if constexpr (AK == A_ROW) arow = a_row_base(P, m0, tid);
+  if constexpr (BKIND == B_NK) brow = b_row_base(P, n0, tid);
+  const int nk = (kend - kbeg + BKS - 1) / BKS;
   if (nk > 0) {
-    load_a<AK>(P, m0, kbeg, kend, tid, va);
-    load_b<BKIND>(P, n0, kbeg, kend, tid, vb);
-    store_a<AK>(lds[0][0], tid, va);
-    store_b<BKIND>(lds[0][1], tid, vb);
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+      load_a<AK>(P, arow, m0, kbeg + u * BKT, kend, tid, va[u]);
+      load_b<BKIND>(P, brow, n0, kbeg + u * BKT, kend, tid, vb[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+      store_a<AK>(lds(0, u, 0), tid, va[u]);
+      store_b<BKIND>(lds(0, u, 1), tid, vb[u]);
+    }
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = (kt + 1) < nk;
     if (more) {
-      load_a<AK>(P, m0, kbeg + (kt + 1) * BKT, kend, tid, va);
-      load_b<BKIND>(P, n0, kbeg + (kt + 1) * BKT, kend, tid, vb);
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) {
+        load_a<AK>(P, arow, m0, kbeg + (kt + 1) * BKS + u * BKT, kend, tid, va[u]);
+        load_b<BKIND>(P, brow, n0, kbeg + (kt + 1) * BKS + u * BKT, kend, tid, vb[u]);
+      }
     }
-    const float* As = lds[cur][0];
-    const float* Bs = lds[cur][1];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float a[4], b[4];
+    for (int u = 0; u < NSUB; ++u) {
+      const float* As = lds(cur, u, 0);
+      const float* Bs = lds(cur, u, 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[(4 * kk + g) * LDS_LD + wm * 64 + i * 16 + r];
+      for (int kk = 0; kk < 4; ++kk) {
+        float a[4], b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * kk + g) * LDS_LD + wn * 64 + j * 16 + r];
+        for (int i = 0; i < 4; ++i) a[i] = As[(4 * kk + g) * LDS_LD + wm * 64 + i * 16 + r];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * kk + g) * LDS_LD + wn * 64 + j * 16 + r];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
     if (more) {
-      store_a<AK>(lds[cur ^ 1][0], tid, va);
-      store_b<BKIND>(lds[cur ^ 1][1], tid, vb);
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) {
+        store_a<AK>(lds(cur ^ 1, u, 0), tid, va[u]);
+        store_b<BKIND>(lds(cur ^ 1, u, 1), tid, vb[u]);
+      }
     }
     __syncthreads();
   }
@@ -295,7 +342,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams P) {
       }
     }
   } else {
-    float* Cbase = P.C + (P.ksplit > 1 ? (long)blockIdx.z * P.M * P.N : 0);
+    float* Cbase = P.C + (P.ksplit > 1 ? (long)zslice * P.M * P.N : 0);
     const long ldc = (P.ksplit > 1) ? P.N : P.ldc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -347,9 +394,22 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 
 template <int AK, int BKIND, int CK>
 int launch(const GemmParams& P, hipStream_t stream) {
-  const int tiles = vts_cdiv(P.M, BM) * vts_cdiv(P.N, BN);
-  dim3 grid(tiles, 1, P.ksplit);
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKIND, CK>), grid, dim3(256), 0, stream, P);
+  const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
+  const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
+  dim3 grid((unsigned)nwg, 1, 1);
+  if (GEMM_LDS_BYTES > 64 * 1024) {
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BKIND, CK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+      if (e != hipSuccess) {
+        vts_set_error("gemm_f32: cannot reserve %zu B of LDS: %s", GEMM_LDS_BYTES, hipGetErrorString(e));
+        return VTS_ERR_HIP;
+      }
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKIND, CK>), grid, dim3(256), GEMM_LDS_BYTES, stream, P);
   VTS_CHECK_LAUNCH("gemm_f32");
   return VTS_OK;
 }
@@ -358,15 +418,21 @@ int launch(const GemmParams& P, hipStream_t stream) {
 
 // ---- internal C++ entry points used by vts_api.hip -------------------------------------------
 
-// Number of K splits that fills the chip for a contraction of length K into an M x N output.
+// Number of K splits for a contraction of length K into an M x N output.  Workgroups are dealt
+// round-robin to the 8 XCDs and the kernel keeps every tile of one k slice on one XCD, so the unit
+// of balance is the XCD: 32 CUs x 4 resident workgroups of this kernel (105 VGPRs, 36 KiB LDS) =
+// 128 slots.  Pick as many whole slices per XCD as fit ONE residency round (a partly filled
+// second round would run alone for a whole slice's duration), the same number on every XCD.
 int vts_gemm_pick_ksplit(int M, int N, long K) {
   const int tiles = vts_cdiv(M, BM) * vts_cdiv(N, BN);
-  if (tiles >= 256 || K <= 512) return 1;
-  long want = (1024 + tiles - 1) / tiles;
-  long maxs = (K + 255) / 256;  // at least 256 contraction elements per split
-  long s = want < maxs ? want : maxs;
+  const int slots_per_xcd = 32 * 4;
+  if (tiles >= 4 * slots_per_xcd || K <= 512) return 1;
+  long per_xcd = slots_per_xcd / tiles;
+  if (per_xcd < 1) per_xcd = 1;
+  long s = 8 * per_xcd;
+  const long maxs = (K + 255) / 256;  // at least 256 contraction elements per split
+  if (s > maxs) s = maxs >= 8 ? maxs / 8 * 8 : maxs;
   if (s < 1) s = 1;
-  if (s > 512) s = 512;
   return (int)s;
 }
 
@@ -388,7 +454,7 @@ static int finish_split(GemmParams P, float* Cfinal, long ldc, int accumulate, h
 static void set_split(GemmParams& P, int ksplit) {
   P.ksplit = ksplit < 1 ? 1 : ksplit;
   long chunk = (P.K + P.ksplit - 1) / P.ksplit;
-  chunk = (chunk + 15) / 16 * 16;
+  chunk = (chunk + BKS - 1) / BKS * BKS;
   P.kchunk = (int)chunk;
   P.ksplit = (int)((P.K + chunk - 1) / chunk);
   if (P.ksplit < 1) P.ksplit = 1;

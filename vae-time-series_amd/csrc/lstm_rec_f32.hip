@@ -12,6 +12,15 @@
 
 namespace {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store (vmcnt(0)), which would drain the prefetched W_hh fragments
+// and the whole step's output stores at every time step.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int H>
 struct RecCfg {
   static constexpr int JT = H / 16;                 // hidden tiles
@@ -59,6 +68,15 @@ __global__ void pack_whh_bwd_kernel(const float* __restrict__ W, float* __restri
     const int col = (wave * C::JPW + jl) * 16 + (lane & 15);
     out[idx] = W[row * H + col];
   }
+}
+
+// Streaming (read-once / write-once) tile16 traffic goes around the L2's normal replacement so that
+// the W_hh image every CU of the XCD re-reads each step stays resident.
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+__device__ __forceinline__ void st_stream(float* p, f32x4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 }
 
 // ---- activations --------------------------------------------------------------------------------
@@ -110,11 +128,21 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
     for (int jl = 0; jl < C::JPW; ++jl)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        gv[jl * 4 + q] = *reinterpret_cast<const f32x4*>(Gt + (long)(q * C::JT + wave * C::JPW + jl) * 256);
+        gv[jl * 4 + q] = ld_stream(Gt + (long)(q * C::JT + wave * C::JPW + jl) * 256);
   };
 
   f32x4 gnext[NT];
   load_g(gnext, 0);
+
+  // W_hh fragment ring: three k-quads ahead of the MFMAs, wrapping into the next step (the
+  // weights do not change with t), so ~48 KiB per wave stay in flight to cover the L2 latency.
+  constexpr bool RING = (C::KQ_F % 4 == 0);
+  f32x4 w0[NT], w1[NT], w2[NT], w3[NT];
+  if constexpr (RING) {
+    load_w(w0, 0);
+    load_w(w1, 1);
+    load_w(w2, 2);
+  }
 
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
@@ -125,19 +153,44 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
 
     if (t > 0) {
       const float* hrow = &hl[cur][r * C::LDH + 4 * g];
-      auto mma = [&](const f32x4 (&w)[NT], int kq) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(hrow + 16 * kq);
+      auto lds_a = [&](int kq) { return *reinterpret_cast<const f32x4*>(hrow + 16 * kq); };
+      auto mma_a = [&](const f32x4 (&w)[NT], const f32x4 a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int i = 0; i < NT; ++i)
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[i][s], acc[i], 0, 0, 0);
       };
-      f32x4 w0[NT], w1[NT];
-      load_w(w0, 0);
-      if constexpr (C::KQ_F == 1) {
+      auto mma = [&](const f32x4 (&w)[NT], int kq) { mma_a(w, lds_a(kq)); };
+      if constexpr (RING) {
+        // the A fragment (h rows) of block kq+1 is read from LDS before the 64 MFMAs of block kq:
+        // with one wave per SIMD an exposed LDS round trip is an idle matrix pipe
+        f32x4 a = lds_a(0);
+        // sched_barrier(0) pins the issue order: left alone, the scheduler sinks every load down
+        // to its first use and the ring degenerates to load-wait-compute.
+        auto block = [&](const f32x4 (&w)[NT], int kq) {
+          const f32x4 an = lds_a((kq + 1) & (C::KQ_F - 1));
+          __builtin_amdgcn_sched_barrier(0);
+          mma_a(w, a);
+          __builtin_amdgcn_sched_barrier(0);
+          a = an;
+        };
+#pragma unroll 1
+        for (int kq = 0; kq < C::KQ_F; kq += 4) {
+          load_w(w3, kq + 3);
+          block(w0, kq);
+          load_w(w0, (kq + 4) & (C::KQ_F - 1));
+          block(w1, kq + 1);
+          load_w(w1, (kq + 5) & (C::KQ_F - 1));
+          block(w2, kq + 2);
+          load_w(w2, (kq + 6) & (C::KQ_F - 1));
+          block(w3, kq + 3);
+        }
+      } else if constexpr (C::KQ_F == 1) {
+        load_w(w0, 0);
         mma(w0, 0);
       } else {
+        load_w(w0, 0);
 #pragma unroll 1
         for (int kq = 0; kq < C::KQ_F; kq += 2) {
           load_w(w1, kq + 1);
@@ -164,11 +217,11 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
         hv[reg] = go[reg] * fast_tanh(c[jl][reg]);
         hl[nxt][(4 * g + reg) * C::LDH + jt * 16 + r] = hv[reg];
       }
-      *reinterpret_cast<f32x4*>(Gt + (long)(0 * C::JT + jt) * 256) = gi;
-      *reinterpret_cast<f32x4*>(Gt + (long)(1 * C::JT + jt) * 256) = gf;
-      *reinterpret_cast<f32x4*>(Gt + (long)(2 * C::JT + jt) * 256) = gg;
-      *reinterpret_cast<f32x4*>(Gt + (long)(3 * C::JT + jt) * 256) = go;
-      *reinterpret_cast<f32x4*>(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4) = c[jl];
+      st_stream(Gt + (long)(0 * C::JT + jt) * 256, gi);
+      st_stream(Gt + (long)(1 * C::JT + jt) * 256, gf);
+      st_stream(Gt + (long)(2 * C::JT + jt) * 256, gg);
+      st_stream(Gt + (long)(3 * C::JT + jt) * 256, go);
+      st_stream(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4, c[jl]);
       if (clast != nullptr && t == T - 1) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -177,14 +230,14 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // h_t tile -> hseq[b, t, :], whole rows, 16 B per lane
     for (int idx = tid; idx < 16 * (H / 4); idx += C::NW * 64) {
       const int row = idx / (H / 4), c4 = idx % (H / 4);
       const int b = b0 + row;
       if (b < B) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(&hl[nxt][row * C::LDH + 4 * c4]);
-        *reinterpret_cast<f32x4*>(hseq + ((long)b * T + t) * H + 4 * c4) = v;
+        st_stream(hseq + ((long)b * T + t) * H + 4 * c4, v);
         if (hlast != nullptr && t == T - 1) *reinterpret_cast<f32x4*>(hlast + (long)b * H + 4 * c4) = v;
       }
     }
@@ -233,47 +286,56 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < KB * JPW; ++i) w[i] = Wv[(blk * KB * JPW + i) * 64];   // i = kq_local*JPW + jl
   };
-  // saved tensors of one step: gates [jl][4], c_t [jl], upstream dh [jl]
-  auto load_step = [&](f32x4 (&gv)[JPW * 4], f32x4 (&cv)[JPW], f32x4 (&dv)[JPW], int t) {
+  // saved tensors of one step: gates [jl][4] and upstream dh [jl]; cell states separately
+  auto load_step = [&](f32x4 (&gv)[JPW * 4], f32x4 (&dv)[JPW], int t) {
     const float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
 #pragma unroll
     for (int jl = 0; jl < JPW; ++jl) {
       const int jt = wave * JPW + jl;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        gv[jl * 4 + q] = *reinterpret_cast<const f32x4*>(Gt + (long)(q * C::JT + jt) * 256);
-      cv[jl] = *reinterpret_cast<const f32x4*>(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+        gv[jl * 4 + q] = ld_stream(Gt + (long)(q * C::JT + jt) * 256);
       if (dhseq != nullptr)
-        dv[jl] = *reinterpret_cast<const f32x4*>(dhseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+        dv[jl] = ld_stream(dhseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
       else
         dv[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
+  auto load_cells = [&](f32x4 (&cv)[JPW], int t) {
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      if (t >= 0)
+        cv[jl] = ld_stream(cseq + ((long)(bt * T + t) * C::JT + wave * JPW + jl) * 256 + lane * 4);
+      else
+        cv[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
 
-  f32x4 gv[JPW * 4], cv[JPW], dv[JPW];      // step t
-  f32x4 gn[JPW * 4], cn[JPW], dn[JPW];      // step t-1 (prefetched)
-  load_step(gn, cn, dn, T - 1);
+  // gates / dh of the step about to be processed, c_t and c_{t-1}: loaded one step ahead
+  f32x4 gn[JPW * 4], dn[JPW], cvt[JPW], cvp[JPW];
+  load_step(gn, dn, T - 1);
+  load_cells(cvt, T - 1);
+  load_cells(cvp, T - 2);
+
+  // W_hh fragment ring, three blocks ahead, wrapping into the next step (see the forward kernel)
+  constexpr bool RING = (NBLK % 4 == 0);
+  f32x4 w0[KB * JPW], w1[KB * JPW], w2[KB * JPW], w3[KB * JPW];
+  if constexpr (RING) {
+    load_w(w0, 0);
+    load_w(w1, 1);
+    load_w(w2, 2);
+  }
 
   for (int t = T - 1; t >= 0; --t) {
     const int cur = t & 1;
     float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
     float* da_s = dal + cur * (16 * C::LDA);
 #pragma unroll
-    for (int i = 0; i < JPW * 4; ++i) gv[i] = gn[i];
-#pragma unroll
-    for (int jl = 0; jl < JPW; ++jl) { cv[jl] = cn[jl]; dv[jl] = dn[jl]; }
-    if (t > 0) load_step(gn, cn, dn, t - 1);   // cn doubles as c_{t-1} of this step
-    else {
-#pragma unroll
-      for (int jl = 0; jl < JPW; ++jl) cn[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-#pragma unroll
     for (int jl = 0; jl < JPW; ++jl) {
       const int jt = wave * JPW + jl;
-      const f32x4 gi = gv[jl * 4 + 0], gf = gv[jl * 4 + 1], gg = gv[jl * 4 + 2], go = gv[jl * 4 + 3];
-      const f32x4 ct = cv[jl], cp = cn[jl];
-      f32x4 dht = dh[jl] + dv[jl];
+      const f32x4 gi = gn[jl * 4 + 0], gf = gn[jl * 4 + 1], gg = gn[jl * 4 + 2], go = gn[jl * 4 + 3];
+      const f32x4 ct = cvt[jl], cp = cvp[jl];
+      f32x4 dht = dh[jl] + dn[jl];
       if (t == T - 1) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -306,13 +368,18 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
       dbs[jl][1] += (daf[0] + daf[1]) + (daf[2] + daf[3]);
       dbs[jl][2] += (dag[0] + dag[1]) + (dag[2] + dag[3]);
       dbs[jl][3] += (dao[0] + dao[1]) + (dao[2] + dao[3]);
-      *reinterpret_cast<f32x4*>(Gt + (long)(0 * C::JT + jt) * 256) = dai;
-      *reinterpret_cast<f32x4*>(Gt + (long)(1 * C::JT + jt) * 256) = daf;
-      *reinterpret_cast<f32x4*>(Gt + (long)(2 * C::JT + jt) * 256) = dag;
-      *reinterpret_cast<f32x4*>(Gt + (long)(3 * C::JT + jt) * 256) = dao;
+      st_stream(Gt + (long)(0 * C::JT + jt) * 256, dai);
+      st_stream(Gt + (long)(1 * C::JT + jt) * 256, daf);
+      st_stream(Gt + (long)(2 * C::JT + jt) * 256, dag);
+      st_stream(Gt + (long)(3 * C::JT + jt) * 256, dao);
     }
     if (t == 0) break;  // dh_{-1} is not needed
-    __syncthreads();
+    // saved tensors of step t-1: in flight during the product below
+    load_step(gn, dn, t - 1);
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) cvt[jl] = cvp[jl];
+    load_cells(cvp, t - 2);
+    lds_barrier();
     // dh_rec[16 x H-slice] = dA[16 x 4H] . W_hh[4H x H-slice]
     f32x4 acc[JPW];
 #pragma unroll
@@ -329,11 +396,23 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
             acc[jl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w[kl * JPW + jl][s], acc[jl], 0, 0, 0);
       }
     };
-    f32x4 w0[KB * JPW], w1[KB * JPW];
-    load_w(w0, 0);
-    if constexpr (NBLK == 1) {
+    if constexpr (RING) {
+#pragma unroll 1
+      for (int blk = 0; blk < NBLK; blk += 4) {
+        load_w(w3, blk + 3);
+        mma(w0, blk);
+        load_w(w0, (blk + 4) & (NBLK - 1));
+        mma(w1, blk + 1);
+        load_w(w1, (blk + 5) & (NBLK - 1));
+        mma(w2, blk + 2);
+        load_w(w2, (blk + 6) & (NBLK - 1));
+        mma(w3, blk + 3);
+      }
+    } else if constexpr (NBLK == 1) {
+      load_w(w0, 0);
       mma(w0, 0);
     } else {
+      load_w(w0, 0);
 #pragma unroll 1
       for (int blk = 0; blk < NBLK; blk += 2) {
         load_w(w1, blk + 1);

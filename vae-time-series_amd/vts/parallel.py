@@ -57,7 +57,8 @@ class DataParallelTrainer:
                  max_buckets: int = 3, optimizer_factory=None):
         self.model = model
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
         self.flat = FlatParameters(model)
         self.opt = (optimizer_factory or (lambda flat: Adam(flat, lr=lr)))(self.flat)
         self.buckets = plan_buckets(self.flat, max_buckets)
@@ -69,7 +70,7 @@ class DataParallelTrainer:
                 if s <= off < e:
                     self._bucket_of[pi] = bi
         self._counts = [sum(1 for b in self._bucket_of.values() if b == bi) for bi in range(len(self.buckets))]
-        if self.world > 1:
+        if self.distributed:   # also with a 1-rank group: the collective path is the same code
             for pi, p in enumerate(self.flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(pi))
 
@@ -89,7 +90,7 @@ class DataParallelTrainer:
         self._pending = []
         loss = forward_loss(self.model, x, y, noise)
         loss.backward()
-        if self.world > 1:
+        if self.distributed:
             # parameters that received no gradient this step never fire their hook
             for bi, left in enumerate(self._remaining):
                 if left > 0:
