@@ -113,6 +113,52 @@ def cpu_baseline(kind, T, C, H, Ld, sample, budget_s=20.0):
                       f"ops incl. fused oneDNN LSTM + autograd + Adam), {el:.1f} s"}
 
 
+def elbo_hbm_roofline(dev, rows=1 << 20, Ld=32, iters=10):
+    """HBM-bound side of the path: fused mixture reparameterisation + ELBO, forward and backward, on
+    enough rows (2^20) for bandwidth to matter.  Algorithmic bytes per window (fp32, each tensor
+    read or written once per pass): forward reads mean, logvar, scale, shape, eps, u (6*4L) +
+    choice (4) + recon, y (8), writes z (4L); backward reads dz and the same six (7*4L), writes
+    four latent gradients (4*4L) + d recon (4): 72*L + 12 + 4 = 2320 B at L = 32."""
+    import vts
+    g = torch.Generator(device=dev).manual_seed(7)
+    mk = lambda *shape: torch.randn(*shape, device=dev, generator=g)
+    mean, logvar = mk(rows, Ld).requires_grad_(True), (mk(rows, Ld) * 0.5).requires_grad_(True)
+    scale = torch.exp(mk(rows, Ld) * 0.3).requires_grad_(True)
+    shape = (mk(rows, Ld).abs() * 0.2 + 0.05).requires_grad_(True)
+    eps, u = mk(rows, Ld), torch.rand(rows, Ld, device=dev, generator=g)
+    choice = torch.rand(rows, device=dev, generator=g)
+    pi = torch.tensor([3.0, 0.01], device=dev, requires_grad=True)
+    recon, y = mk(rows, 1).requires_grad_(True), mk(rows, 1)
+    dz = mk(rows, Ld)
+
+    def once():
+        z = vts.reparameterize_mixture(mean, logvar, scale, shape, pi, choice, eps, u)
+        loss = vts.mixture_elbo(recon, y, mean, logvar, scale, shape, pi, threshold=0.8, beta=0.001)
+        torch.autograd.backward([z, loss], [dz, torch.ones((), device=dev)])
+        for t in (mean, logvar, scale, shape, pi, recon):
+            t.grad = None
+
+    from vts import _lib as L
+    once()
+    torch.cuda.synchronize()
+    L.timer.reset()
+    L.timer.enabled = True
+    for _ in range(iters):
+        once()
+    torch.cuda.synchronize()
+    L.timer.enabled = False
+    summ = L.timer.summary()
+    L.timer.reset()
+    per = {k: round(v[1] / v[0], 4) for k, v in summ.items()}
+    ms = sum(per.values())
+    bytes_alg = rows * (72 * Ld + 16)
+    gbps = bytes_alg / (ms * 1e-3) / 1e9
+    return {"kernels_ms": per, "family": "mixture", "rows": rows, "ms": round(ms, 4), "bound": "hbm",
+            "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+            "note": "sum of the four kernels' device time (HIP events on the launch stream); "
+                    "algorithmic bytes = rows * (72*L + 16)"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,12 +215,13 @@ def main():
         summ = L.timer.summary()
         kernels = {}
         for name, (n, tot_ms) in summ.items():
-            flops = sum(per[name]) / len(per[name])   # mean algorithmic FLOPs per launch of this name
             avg_ms = tot_ms / n
             kernels[name] = {"launches_per_step": n // a.steps, "avg_ms": round(avg_ms, 4),
-                             "share_of_step": round(tot_ms / a.steps / ms_per_step, 4),
-                             "tflops": round(flops / (avg_ms * 1e-3) / 1e12, 2)}
-        dom = max(summ, key=lambda k: summ[k][1])
+                             "share_of_step": round(tot_ms / a.steps / ms_per_step, 4)}
+            if name in per:   # MFMA kernels: mean algorithmic FLOPs per launch of this name
+                flops = sum(per[name]) / len(per[name])
+                kernels[name]["tflops"] = round(flops / (avg_ms * 1e-3) / 1e12, 2)
+        dom = max((k for k in summ if k in per), key=lambda k: summ[k][1])
         dom_tflops = kernels[dom]["tflops"]
         out = {
             "metric": "train windows/sec (fwd+bwd+ELBO+Adam)", "value": round(value, 1), "unit": "windows/s",
@@ -194,6 +241,8 @@ def main():
             "kernels": kernels,
             "final_loss": final_loss,
         }
+        if world == 1:
+            out["elbo_hbm_roofline"] = elbo_hbm_roofline(dev)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model, a.T, a.C, a.H, a.L, a.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -439,13 +439,23 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
   }
 }
 
-__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int N,
-                                       long pitch, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// out[n] (+)= sum_p part[p * pitch + n].  One workgroup per 64 columns; its 4 waves split the
+// partials (coalesced 256-byte rows) and combine through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part,
+                                                              float* __restrict__ out, int nparts, int N,
+                                                              long pitch, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(long)p * pitch + n];
-  out[n] = accumulate ? out[n] + s : s;
+  if (n < N)
+    for (int p = wave; p < nparts; p += 4) s += part[(long)p * pitch + n];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[n] = accumulate ? out[n] + tot : tot;
+  }
 }
 
 template <int H>
@@ -517,7 +527,7 @@ int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const floa
 
 int vts_colsum_partials(const float* part, float* out, int nparts, int N, long pitch, int accumulate,
                         hipStream_t stream) {
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(vts_cdiv(N, 256)), dim3(256), 0, stream, part, out, nparts, N,
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(vts_cdiv(N, 64)), dim3(256), 0, stream, part, out, nparts, N,
                      pitch, accumulate);
   VTS_CHECK_LAUNCH("colsum_partials");
   return VTS_OK;

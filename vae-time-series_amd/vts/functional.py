@@ -228,7 +228,7 @@ class _Reparam(torch.autograd.Function):
         mean, logvar, scale, shape, eps, u, choice = [_c(t) for t in (mean, logvar, scale, shape, eps, u, choice)]
         pi_d = None if pi is None else pi.detach().contiguous()
         z = torch.empty(B, Ld, device=ref.device, dtype=torch.float32)
-        L.check(lib.vts_reparam_fwd(family, L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape), L.ptr(eps),
+        L.check(L.timer.call("reparam_fwd", lib.vts_reparam_fwd, family, L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape), L.ptr(eps),
                                     L.ptr(u), L.ptr(choice), L.ptr(pi_d), L.ptr(z), B, Ld, L.stream()),
                 "vts_reparam_fwd")
         ctx.family = family
@@ -248,7 +248,7 @@ class _Reparam(torch.autograd.Function):
             dmean, dlogvar = new(), new()
         if fam != L.GAUSSIAN:
             dscale, dshape = new(), new()
-        L.check(lib.vts_reparam_bwd(fam, L.ptr(dz), L.ptr(logvar), L.ptr(scale), L.ptr(shape), L.ptr(eps), L.ptr(u),
+        L.check(L.timer.call("reparam_bwd", lib.vts_reparam_bwd, fam, L.ptr(dz), L.ptr(logvar), L.ptr(scale), L.ptr(shape), L.ptr(eps), L.ptr(u),
                                     L.ptr(choice), L.ptr(pi_d), L.ptr(dmean), L.ptr(dlogvar), L.ptr(dscale),
                                     L.ptr(dshape), B, Ld, L.stream()), "vts_reparam_bwd")
         return None, dmean, dlogvar, dscale, dshape, None, None, None, None
@@ -297,7 +297,7 @@ class _Elbo(torch.autograd.Function):
         state = torch.empty(16, device=recon.device, dtype=torch.float32)
         ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
         ws = L.workspace(ws_bytes, recon.device)
-        L.check(lib.vts_elbo_fwd(family, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale),
+        L.check(L.timer.call("elbo_fwd", lib.vts_elbo_fwd, family, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale),
                                  L.ptr(shape), L.ptr(pi), threshold, beta, L.ptr(state), L.wptr(ws), ws_bytes, B, fs,
                                  Ld, L.stream()), "vts_elbo_fwd")
         ctx.family, ctx.threshold, ctx.dims = family, threshold, (B, fs, Ld)
@@ -321,7 +321,7 @@ class _Elbo(torch.autograd.Function):
             dscale, dshape = new(), new()
         if fam == L.MIXTURE:
             dpi = torch.empty(2, device=dev, dtype=torch.float32)
-        L.check(lib.vts_elbo_bwd(fam, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape),
+        L.check(L.timer.call("elbo_bwd", lib.vts_elbo_bwd, fam, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape),
                                  L.ptr(state), L.ptr(gout), ctx.threshold, L.ptr(drecon), L.ptr(dmean),
                                  L.ptr(dlogvar), L.ptr(dscale), L.ptr(dshape), L.ptr(dpi), B, fs, Ld, L.stream()),
                 "vts_elbo_bwd")
