@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--C", type=int, default=370)
     ap.add_argument("--H", type=int, default=256)
     ap.add_argument("--L", type=int, default=32)
+    ap.add_argument("--mode", default="f32", choices=["f32", "bf16x3"],
+                    help="arithmetic of the LSTM's dense products (recurrence, heads and ELBO are f32 in both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="windows in the CPU baseline sample")
     return ap.parse_args()
@@ -179,6 +181,7 @@ def main():
     import vts
     from vts import _lib as L
 
+    vts.set_mode(a.mode)
     torch.manual_seed(1234)                     # identical replicas on every rank
     model = vts.build_model(a.model, a.C, a.H, a.L, 1).to(dev)
     model.train()
@@ -226,12 +229,13 @@ def main():
         out = {
             "metric": "train windows/sec (fwd+bwd+ELBO+Adam)", "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.mode == "f32" else "f32 recurrence/heads/ELBO + bf16x3-split GEMMs (fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{a.model} LSTM-VAE train step, LD2011-shaped windows: {a.batch} windows/GPU x "
                                    f"{a.T} steps x {a.C} channels, hidden {a.H}, latent {a.L}, future_steps 1",
                        "model_kind": a.model, "windows_per_gpu": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-3) inside the timed step",
+                       "parallelism": f"dp{world}", "gemm_mode": a.mode, "optimizer": "Adam(lr=1e-3) inside the timed step",
                        "noise": "drawn on device every step"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": dom_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None},

@@ -11,6 +11,15 @@ from oracle import ref_torch as R
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+MODES = ["f32", "bf16x3"]   # arithmetic of the LSTM's dense products; both carry the 1e-4 claim
+
+
+@pytest.fixture
+def mode(request):
+    import vts
+    vts.set_mode(request.param)
+    yield request.param
+    vts.set_mode("f32")
 
 
 def _dev():
@@ -65,8 +74,9 @@ OUT_NAMES = {"gaussian": ["recon", "mean", "logvar"], "gpd": ["recon", "scale", 
              "mixture": ["recon", "mean", "logvar", "scale", "shape"]}
 
 
+@pytest.mark.parametrize("mode", MODES, indirect=True)
 @pytest.mark.parametrize("name", WELL_CONDITIONED)
-def test_golden_loss_and_gradients(golden, name):
+def test_golden_loss_and_gradients(golden, name, mode):
     """Reference fixtures: loss within 1e-4 relative, every gradient within 1e-4 L2-relative."""
     g = golden(name)
     kind = kind_of(name)
@@ -132,7 +142,8 @@ def test_clamped_shape_gets_zero_gradient(golden):
     (40, 12, 370, 128, 2),   # LD2011 channel count (C % 4 == 2)
     (48, 9, 20, 256, 3),     # headline hidden size
 ])
-def test_lstm_matches_oracle(B, T, C, H, layers):
+@pytest.mark.parametrize("mode", MODES, indirect=True)
+def test_lstm_matches_oracle(B, T, C, H, layers, mode):
     import vts
     dev = _dev()
     g = torch.Generator().manual_seed(B * 1000 + T)
@@ -158,7 +169,8 @@ def test_lstm_matches_oracle(B, T, C, H, layers):
         assert l2_rel(p.grad, getattr(ref, k).grad) < TOL, k
 
 
-def test_lstm_input_gradient():
+@pytest.mark.parametrize("mode", MODES, indirect=True)
+def test_lstm_input_gradient(mode):
     import vts
     dev = _dev()
     g = torch.Generator().manual_seed(5)
@@ -348,7 +360,8 @@ def test_adam_trajectory(golden, kind):
             assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-6, k
 
 
-def test_large_batch_against_oracle_slice():
+@pytest.mark.parametrize("mode", MODES, indirect=True)
+def test_large_batch_against_oracle_slice(mode):
     """Headline channel/hidden sizes on a batch the CPU oracle finishes in seconds."""
     import vts
     dev = _dev()

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--only", default="")
+    ap.add_argument("--mode", type=int, default=0)
     a = ap.parse_args()
     from vts import _lib as L
     if a.lib:
@@ -54,23 +55,24 @@ def main():
     wg_b = max(lib.vts_lstm_wgrad_workspace_bytes(B, T, Cin, H), lib.vts_lstm_wgrad_workspace_bytes(B, T, H, H))
     wg = L.workspace(wg_b, dev)
     st = L.stream()
+    MODE = a.mode
     inproj_f = 2.0 * B * T * Cin * 4 * H
     rec_f = 2.0 * B * T * H * 4 * H
 
     stages = [
         ("inproj_fwd", inproj_f, lambda: lib.vts_lstm_inproj_fwd(L.ptr(x), L.ptr(w_ih), L.ptr(b), L.ptr(b),
-                                                                   L.wptr(gates), B, T, Cin, H, 0, st)),
+                                                                   L.wptr(gates), B, T, Cin, H, MODE, st)),
         ("recurrent_fwd", rec_f, lambda: lib.vts_lstm_recurrent_fwd(L.wptr(gates), L.wptr(cells), L.ptr(hseq),
                                                                       L.ptr(h_last), None, L.ptr(w_hh), L.wptr(rws),
                                                                       rws_b, B, T, H, 0, st)),
         ("recurrent_bwd", rec_f, lambda: lib.vts_lstm_recurrent_bwd(L.wptr(gates), L.wptr(cells), None,
                                                                       L.ptr(dh_last), None, L.ptr(w_hh), L.ptr(db),
                                                                       L.ptr(db), 0, L.wptr(rws), rws_b, B, T, H, 0, st)),
-        ("dgrad(H)", rec_f, lambda: lib.vts_lstm_dgrad(L.wptr(gates), L.ptr(w_ih2), L.wptr(dx), B, T, H, H, 0, st)),
+        ("dgrad(H)", rec_f, lambda: lib.vts_lstm_dgrad(L.wptr(gates), L.ptr(w_ih2), L.wptr(dx), B, T, H, H, MODE, st)),
         ("wgrad_ih", inproj_f, lambda: lib.vts_lstm_wgrad(L.wptr(gates), L.ptr(x), 0, L.ptr(dw_ih), 0, L.wptr(wg),
-                                                          wg_b, B, T, Cin, H, 0, st)),
+                                                          wg_b, B, T, Cin, H, MODE, st)),
         ("wgrad_hh", rec_f, lambda: lib.vts_lstm_wgrad(L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw_hh), 0, L.wptr(wg),
-                                                       wg_b, B, T, H, H, 0, st)),
+                                                       wg_b, B, T, H, H, MODE, st)),
     ]
     for name, flops, fn in stages:
         if a.only and a.only not in name:

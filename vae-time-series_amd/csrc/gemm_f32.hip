@@ -55,7 +55,8 @@ struct GemmParams {
   float* aux;          // act 3: [M][N] 1.0 where pre-activation >= 1e-6 (gradient passes)
   int accumulate;      // C += result (ksplit == 1 only)
   int ksplit;          // >1: grid.z slabs of M*N floats at C
-  int kchunk;          // K elements per split (multiple of 16)
+  int kchunk;          // K elements per split (multiple of 32)
+  int mode;            // 0 = f32 MFMA, 1 = bf16x3 split on the bf16 MFMA
 };
 
 __device__ __forceinline__ long window_row(int m, int T, int Bwin, int tshift, bool& valid) {
@@ -219,6 +220,100 @@ __device__ __forceinline__ void store_b(float* __restrict__ Bs, int tid, const f
   }
 }
 
+// Workgroup -> (m tile, n tile, k slice).  Workgroups whose ids are equal mod 8 share an XCD
+// (and its L2): all tiles that read the same operand panel - the n tiles of one m tile, or
+// every tile of one k slice - are given ids equal mod 8 and adjacent in time, so the panel is
+// fetched into one L2 once instead of into all eight.  Returns false for padding workgroups.
+__device__ __forceinline__ bool map_workgroup(const GemmParams& P, int& m0, int& n0, int& zslice, int& kbeg,
+                                              int& kend) {
+  const int tiles_n = (P.N + BN - 1) / BN;
+  const int tiles_m = (P.M + BM - 1) / BM;
+  int tile;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  if (P.ksplit > 1) {
+    const int per = tiles_m * tiles_n;
+    zslice = (j / per) * 8 + xcd;
+    tile = j % per;
+    if (zslice >= P.ksplit) return false;
+  } else {
+    const int mt = (j / tiles_n) * 8 + xcd;
+    if (mt >= tiles_m) return false;
+    tile = mt * tiles_n + j % tiles_n;
+    zslice = 0;
+  }
+  m0 = (tile / tiles_n) * BM;
+  n0 = (tile % tiles_n) * BN;
+  kbeg = zslice * P.kchunk;
+  kend = min(P.K, kbeg + P.kchunk);
+  return true;
+}
+
+// Accumulator tiles -> memory.  acc[i][j] is the 16x16 tile (i, j) of this wave's 64x64 block in the
+// v_mfma 16x16 C/D layout (lane l: column l&15, rows 4*(l>>4)..+3), the same for every dtype.
+template <int CK>
+__device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4], int m0, int n0, int zslice,
+                                         int wm, int wn, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  if constexpr (CK == C_T16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mt = (m0 + wm * 64 + i * 16) >> 4;
+      if (mt * 16 >= P.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nbase = n0 + wn * 64 + j * 16;
+        if (nbase >= P.N) continue;
+        f32x4 v = acc[i][j];
+        float bsum = 0.f;
+        if (P.bias0) bsum += P.bias0[nbase + r];
+        if (P.bias1) bsum += P.bias1[nbase + r];
+        v += bsum;
+        float* dst = P.C + ((long)mt * (P.N >> 4) + (nbase >> 4)) * 256 + lane * 4;
+        if (P.accumulate) {
+          const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
+          v += old;
+        }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  } else {
+    float* Cbase = P.C + (P.ksplit > 1 ? (long)zslice * P.M * P.N : 0);
+    const long ldc = (P.ksplit > 1) ? P.N : P.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r;
+        if (col >= P.N) continue;
+        float bsum = 0.f;
+        if (P.ksplit == 1) {
+          if (P.bias0) bsum += P.bias0[col];
+          if (P.bias1) bsum += P.bias1[col];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = m0 + wm * 64 + i * 16 + 4 * g + reg;
+          if (row >= P.M) continue;
+          float v = acc[i][j][reg] + bsum;
+          if (P.ksplit == 1) {
+            if (P.act == 1) v = fmaxf(v, 0.f);
+            else if (P.act == 2) v = expf(v);
+            else if (P.act == 3) {
+              if (P.aux) P.aux[(long)row * ldc + col] = (v >= 1e-6f) ? 1.f : 0.f;
+              v = fmaxf(v, 1e-6f);
+            } else if (P.act == 4) {
+              v = fmaxf(v, 0.f);
+              if (P.keep) v = v * P.keep[(long)row * ldc + col] * P.keep_scale;
+            }
+            if (P.accumulate) v += Cbase[(long)row * ldc + col];
+          }
+          Cbase[(long)row * ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
 template <int AK, int BKIND, int CK>
 __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];   // [buf][sub][A|B][BKT * LDS_LD]
@@ -229,31 +324,8 @@ __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmP
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 15, g = lane >> 4;
 
-  // Workgroup -> (m tile, n tile, k slice).  Workgroups whose ids are equal mod 8 share an XCD
-  // (and its L2): all tiles that read the same operand panel - the n tiles of one m tile, or
-  // every tile of one k slice - are given ids equal mod 8 and adjacent in time, so the panel is
-  // fetched into one L2 once instead of into all eight.
-  const int tiles_n = (P.N + BN - 1) / BN;
-  const int tiles_m = (P.M + BM - 1) / BM;
-  int tile, zslice;
-  {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    if (P.ksplit > 1) {
-      const int per = tiles_m * tiles_n;
-      zslice = (j / per) * 8 + xcd;
-      tile = j % per;
-      if (zslice >= P.ksplit) return;
-    } else {
-      const int mt = (j / tiles_n) * 8 + xcd;
-      if (mt >= tiles_m) return;
-      tile = mt * tiles_n + j % tiles_n;
-      zslice = 0;
-    }
-  }
-  const int m0 = (tile / tiles_n) * BM;
-  const int n0 = (tile % tiles_n) * BN;
-  const int kbeg = zslice * P.kchunk;
-  const int kend = min(P.K, kbeg + P.kchunk);
+  int m0, n0, zslice, kbeg, kend;
+  if (!map_workgroup(P, m0, n0, zslice, kbeg, kend)) return;
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -318,65 +390,218 @@ __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmP
     __syncthreads();
   }
 
-  // ---- epilogue
-  if constexpr (CK == C_T16) {
+  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane);
+}
+
+// =================================================================================================
+// bf16x3 variant: the same contraction on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, 16x the
+// f32 MFMA rate) at fp32-level accuracy.  Every fp32 operand x is split while it is staged into
+// LDS, x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and each product is evaluated as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation (the dropped a_lo*b_lo term and the
+// split residuals are ~2^-16 relative).  Tile 128 x 128 x 32, LDS rows hold 32 k values (k
+// contiguous, 80-byte row pitch) in two planes (hi, lo) per operand; the C/D layout of the 16x16
+// bf16 MFMA equals the f32 one, so mapping and epilogue are shared with the f32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BK3 = 32;                 // k elements per main-loop iteration
+constexpr int ROWB = 80;                // LDS row pitch in bytes (32 bf16 + 16 B pad)
+constexpr int PLANE = 128 * ROWB;       // one plane (hi or lo) of one operand tile
+constexpr size_t GEMM3_LDS_BYTES = 4ul * PLANE;   // A hi, A lo, B hi, B lo
+
+// x -> (hi, lo) for two values at a time: one packed round-to-nearest conversion gives both hi
+// halves, two integer ops widen them back to fp32, one packed conversion rounds the residuals
+// (6 VALU instructions per pair; v_cvt_pk_bf16_f32 has no builtin, a plain cast costs ~9).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+  lo = cvt_pk_bf16(x0 - h0, x1 - h1);
+}
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
+  split2(x0, x1, hi.x, lo.x);
+  split2(x2, x3, hi.y, lo.y);
+}
+
+__device__ __forceinline__ void load4(const float* __restrict__ p, int nvalid, float (&v)[4]) {
+  if (nvalid >= 4) {
+    const f32x4_u x = *reinterpret_cast<const f32x4_u*>(p);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int mt = (m0 + wm * 64 + i * 16) >> 4;
-      if (mt * 16 >= P.M) continue;
+    for (int i = 0; i < 4; ++i) v[i] = (i < nvalid) ? p[i] : 0.f;
+  }
+}
+
+// 16 fp32 values per thread for one 128 x 32 operand tile; v[s][i], meaning depends on the kind
+// (see store3).  OPK: 0 = k-contiguous rows (A_ROW, B_NK), 1 = row-contiguous (A_COL, B_KN),
+// 2 = tile16 [rows, K] (A_T16), 3 = tile16 [K, rows] (A_T16T).
+template <int OPK>
+__device__ __forceinline__ void load3(const GemmParams& P, bool is_a, const float* rowptr, int r0, int k0, int kend,
+                                      int tid, float (&v)[4][4]) {
+  const float* base = is_a ? P.A : P.B;
+  const long ld = is_a ? P.lda : P.ldb;
+  const int R = is_a ? P.M : P.N;          // extent of the row (m or n) index
+  if constexpr (OPK == 0) {
+    const int k = k0 + (tid & 1) * 16;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nbase = n0 + wn * 64 + j * 16;
-        if (nbase >= P.N) continue;
-        f32x4 v = acc[i][j];
-        float bsum = 0.f;
-        if (P.bias0) bsum += P.bias0[nbase + r];
-        if (P.bias1) bsum += P.bias1[nbase + r];
-        v += bsum;
-        float* dst = P.C + ((long)mt * (P.N >> 4) + (nbase >> 4)) * 256 + lane * 4;
-        if (P.accumulate) {
-          const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
-          v += old;
-        }
-        *reinterpret_cast<f32x4*>(dst) = v;
-      }
+    for (int s = 0; s < 4; ++s) {
+      const int nv = (rowptr != nullptr) ? min(4, kend - (k + 4 * s)) : 0;
+      if (nv > 0) load4(rowptr + k + 4 * s, nv, v[s]);
+      else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f; }
+    }
+  } else if constexpr (OPK == 1) {
+    const int rr = r0 + (tid & 31) * 4;
+    const int kb = k0 + (tid >> 5) * 4;
+    const int map = is_a ? 0 : P.b_map;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = kb + s;
+      bool valid = k < kend;
+      long row = k;
+      if (map && valid) row = window_row(k, P.T, P.Bwin, P.b_tshift, valid);
+      const int nv = valid ? min(4, R - rr) : 0;
+      if (nv > 0) load4(base + row * ld + rr, nv, v[s]);
+      else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f; }
+    }
+  } else if constexpr (OPK == 2) {
+    const int blk = tid >> 4;
+    const int rt = (r0 >> 4) + (blk >> 1), kt = (k0 >> 4) + (blk & 1);
+    const int g = (tid & 15) >> 2, cq = tid & 3;
+    const bool valid = (rt * 16 < R) && (kt * 16 < kend);
+    const float* p = base + ((long)rt * (P.K >> 4) + kt) * 256 + (g * 16 + 4 * cq) * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (valid) load4(p + 4 * s, 4, v[s]);
+      else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f; }
     }
   } else {
-    float* Cbase = P.C + (P.ksplit > 1 ? (long)zslice * P.M * P.N : 0);
-    const long ldc = (P.ksplit > 1) ? P.N : P.ldc;
+    const int blk = tid >> 4;
+    const int kt = (k0 >> 4) + (blk >> 3), rt = (r0 >> 4) + (blk & 7);
+    const int g = (tid & 15) >> 2, cq = tid & 3;
+    const bool valid = (rt * 16 < R) && (kt * 16 < kend);
+    const float* p = base + ((long)kt * (R >> 4) + rt) * 256 + (g * 16 + 4 * cq) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + r;
-        if (col >= P.N) continue;
-        float bsum = 0.f;
-        if (P.ksplit == 1) {
-          if (P.bias0) bsum += P.bias0[col];
-          if (P.bias1) bsum += P.bias1[col];
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = m0 + wm * 64 + i * 16 + 4 * g + reg;
-          if (row >= P.M) continue;
-          float v = acc[i][j][reg] + bsum;
-          if (P.ksplit == 1) {
-            if (P.act == 1) v = fmaxf(v, 0.f);
-            else if (P.act == 2) v = expf(v);
-            else if (P.act == 3) {
-              if (P.aux) P.aux[(long)row * ldc + col] = (v >= 1e-6f) ? 1.f : 0.f;
-              v = fmaxf(v, 1e-6f);
-            } else if (P.act == 4) {
-              v = fmaxf(v, 0.f);
-              if (P.keep) v = v * P.keep[(long)row * ldc + col] * P.keep_scale;
-            }
-            if (P.accumulate) v += Cbase[(long)row * ldc + col];
-          }
-          Cbase[(long)row * ldc + col] = v;
-        }
-      }
+    for (int s = 0; s < 4; ++s) {
+      if (valid) load4(p + 4 * s, 4, v[s]);
+      else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f; }
     }
   }
+}
+
+// Split and write the 16 values into the hi / lo planes of the operand's LDS tile.
+template <int OPK>
+__device__ __forceinline__ void store3(char* __restrict__ hi, char* __restrict__ lo, int tid, const float (&v)[4][4]) {
+  if constexpr (OPK == 0) {          // v[s][i] = (row tid>>1, k = 16*(tid&1) + 4s + i)
+    const int off = (tid >> 1) * ROWB + (tid & 1) * 32;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint2 h, l;
+      split4(v[s][0], v[s][1], v[s][2], v[s][3], h, l);
+      *reinterpret_cast<uint2*>(hi + off + 8 * s) = h;
+      *reinterpret_cast<uint2*>(lo + off + 8 * s) = l;
+    }
+  } else if constexpr (OPK == 1 || OPK == 2) {   // v[s][i] = (row base + i, k = kbase + s)
+    int rowb, kbyte;
+    if constexpr (OPK == 1) { rowb = (tid & 31) * 4; kbyte = (tid >> 5) * 8; }
+    else { const int blk = tid >> 4; rowb = (blk >> 1) * 16 + ((tid & 15) >> 2) * 4; kbyte = ((blk & 1) * 16 + (tid & 3) * 4) * 2; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 h, l;
+      split4(v[0][i], v[1][i], v[2][i], v[3][i], h, l);
+      *reinterpret_cast<uint2*>(hi + (rowb + i) * ROWB + kbyte) = h;
+      *reinterpret_cast<uint2*>(lo + (rowb + i) * ROWB + kbyte) = l;
+    }
+  } else {                           // v[s][i] = (row base + s, k = kbase + i)
+    const int blk = tid >> 4;
+    const int rowb = (blk & 7) * 16 + (tid & 3) * 4;
+    const int kbyte = ((blk >> 3) * 16 + ((tid & 15) >> 2) * 4) * 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint2 h, l;
+      split4(v[s][0], v[s][1], v[s][2], v[s][3], h, l);
+      *reinterpret_cast<uint2*>(hi + (rowb + s) * ROWB + kbyte) = h;
+      *reinterpret_cast<uint2*>(lo + (rowb + s) * ROWB + kbyte) = l;
+    }
+  }
+}
+
+template <int AK> struct OpKindA { static constexpr int v = (AK == A_ROW) ? 0 : (AK == A_COL) ? 1 : (AK == A_T16) ? 2 : 3; };
+template <int BKIND> struct OpKindB { static constexpr int v = (BKIND == B_NK) ? 0 : 1; };
+
+template <int AK, int BKIND, int CK>
+__global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(const GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) char lds3[];   // [A hi | A lo | B hi | B lo]
+  char* a_hi = lds3;
+  char* a_lo = lds3 + PLANE;
+  char* b_hi = lds3 + 2 * PLANE;
+  char* b_lo = lds3 + 3 * PLANE;
+  constexpr int OA = OpKindA<AK>::v, OB = OpKindB<BKIND>::v;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  int m0, n0, zslice, kbeg, kend;
+  if (!map_workgroup(P, m0, n0, zslice, kbeg, kend)) return;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* arow = nullptr;
+  const float* brow = nullptr;
+  if constexpr (AK == A_ROW) arow = a_row_base(P, m0, tid);
+  if constexpr (BKIND == B_NK) brow = b_row_base(P, n0, tid);
+
+  float va[4][4], vb[4][4];
+  const int nk = (kend - kbeg + BK3 - 1) / BK3;
+  if (nk > 0) {
+    load3<OA>(P, true, arow, m0, kbeg, kend, tid, va);
+    load3<OB>(P, false, brow, n0, kbeg, kend, tid, vb);
+    store3<OA>(a_hi, a_lo, tid, va);
+    store3<OB>(b_hi, b_lo, tid, vb);
+  }
+  __syncthreads();
+  const int a_off = (wm * 64 + r) * ROWB + g * 16;
+  const int b_off = (wn * 64 + r) * ROWB + g * 16;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      load3<OA>(P, true, arow, m0, kbeg + (kt + 1) * BK3, kend, tid, va);
+      load3<OB>(P, false, brow, n0, kbeg + (kt + 1) * BK3, kend, tid, vb);
+    }
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + a_off + i * 16 * ROWB);
+      al[i] = *reinterpret_cast<const bf16x8*>(a_lo + a_off + i * 16 * ROWB);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + b_off + j * 16 * ROWB);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + b_off + j * 16 * ROWB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();           // every wave is done reading this k chunk
+    if (more) {
+      store3<OA>(a_hi, a_lo, tid, va);
+      store3<OB>(b_hi, b_lo, tid, vb);
+    }
+    __syncthreads();
+  }
+  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane);
 }
 
 // Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C.
@@ -393,7 +618,17 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 }
 
 template <int AK, int BKIND, int CK>
+int launch3(const GemmParams& P, hipStream_t stream) {
+  const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
+  const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, BKIND, CK>), dim3((unsigned)nwg), dim3(256), GEMM3_LDS_BYTES, stream, P);
+  VTS_CHECK_LAUNCH("gemm_bf16x3");
+  return VTS_OK;
+}
+
+template <int AK, int BKIND, int CK>
 int launch(const GemmParams& P, hipStream_t stream) {
+  if (P.mode == 1) return launch3<AK, BKIND, CK>(P, stream);
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
   dim3 grid((unsigned)nwg, 1, 1);
@@ -423,9 +658,9 @@ int launch(const GemmParams& P, hipStream_t stream) {
 // of balance is the XCD: 32 CUs x 4 resident workgroups of this kernel (105 VGPRs, 36 KiB LDS) =
 // 128 slots.  Pick as many whole slices per XCD as fit ONE residency round (a partly filled
 // second round would run alone for a whole slice's duration), the same number on every XCD.
-int vts_gemm_pick_ksplit(int M, int N, long K) {
+int vts_gemm_pick_ksplit(int M, int N, long K, int mode) {
   const int tiles = vts_cdiv(M, BM) * vts_cdiv(N, BN);
-  const int slots_per_xcd = 32 * 4;
+  const int slots_per_xcd = 32 * (mode == 1 ? 3 : 4);   // bf16x3 kernel: 160 VGPRs -> 3 workgroups per CU
   if (tiles >= 4 * slots_per_xcd || K <= 512) return 1;
   long per_xcd = slots_per_xcd / tiles;
   if (per_xcd < 1) per_xcd = 1;
@@ -454,7 +689,7 @@ static int finish_split(GemmParams P, float* Cfinal, long ldc, int accumulate, h
 static void set_split(GemmParams& P, int ksplit) {
   P.ksplit = ksplit < 1 ? 1 : ksplit;
   long chunk = (P.K + P.ksplit - 1) / P.ksplit;
-  chunk = (chunk + BKS - 1) / BKS * BKS;
+  chunk = (chunk + 31) / 32 * 32;
   P.kchunk = (int)chunk;
   P.ksplit = (int)((P.K + chunk - 1) / chunk);
   if (P.ksplit < 1) P.ksplit = 1;
@@ -462,8 +697,9 @@ static void set_split(GemmParams& P, int ksplit) {
 
 // LSTM input projection: G[tile16 of [Mp, 4H]] = X[window rows] . W^T + b0 + b1
 int vts_gemm_inproj(const float* X, const float* W, const float* b0, const float* b1, float* G, int Bwin, int T,
-                    int Cin, int N4H, hipStream_t stream) {
+                    int Cin, int N4H, int mode, hipStream_t stream) {
   GemmParams P{};
+  P.mode = mode;
   const int Bp = (Bwin + 15) / 16 * 16;
   P.A = X; P.B = W; P.C = G;
   P.M = Bp * T; P.N = N4H; P.K = Cin;
@@ -476,8 +712,9 @@ int vts_gemm_inproj(const float* X, const float* W, const float* b0, const float
 
 // dX[tile16 of [Mp, Cin]] (+)= dG[tile16 of [Mp, 4H]] . W[4H][Cin]
 int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int T, int Cin, int N4H,
-                       int accumulate, hipStream_t stream) {
+                       int accumulate, int mode, hipStream_t stream) {
   GemmParams P{};
+  P.mode = mode;
   const int Bp = (Bwin + 15) / 16 * 16;
   P.A = dG; P.B = W; P.C = dX;
   P.M = Bp * T; P.N = Cin; P.K = N4H;
@@ -489,8 +726,9 @@ int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int
 
 // dW[4H][F] = sum over window rows m' of dG[m'][:]^T . X[window row(m', tshift)][:F]
 int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
-                       int F, long ldx, int N4H, int tshift, int accumulate, hipStream_t stream) {
+                       int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream) {
   GemmParams P{};
+  P.mode = mode;
   const int Bp = (Bwin + 15) / 16 * 16;
   P.A = dG; P.B = X;
   P.M = N4H; P.N = F; P.K = Bp * T;

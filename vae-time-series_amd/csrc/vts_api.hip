@@ -6,14 +6,14 @@
 #include <string.h>
 
 // ---- internal entry points (gemm_f32.hip, lstm_rec_f32.hip, elementwise.hip) -------------------
-int vts_gemm_pick_ksplit(int M, int N, long K);
+int vts_gemm_pick_ksplit(int M, int N, long K, int mode);
 size_t vts_gemm_slab_bytes(int M, int N, int ksplit);
 int vts_gemm_inproj(const float* X, const float* W, const float* b0, const float* b1, float* G, int Bwin, int T,
-                    int Cin, int N4H, hipStream_t stream);
+                    int Cin, int N4H, int mode, hipStream_t stream);
 int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int T, int Cin, int N4H,
-                       int accumulate, hipStream_t stream);
+                       int accumulate, int mode, hipStream_t stream);
 int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
-                       int F, long ldx, int N4H, int tshift, int accumulate, hipStream_t stream);
+                       int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream);
 int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
                         int N, int K, int act, const float* keep, float keep_scale, float* aux, hipStream_t stream);
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
@@ -68,12 +68,12 @@ void vts_set_error(const char* fmt, ...) {
 static inline size_t round256(size_t n) { return (n + 255) & ~(size_t)255; }
 static inline long pad16(long b) { return (b + 15) / 16 * 16; }
 
-#define VTS_MODE_CHECK(mode)                                                                       \
-  do {                                                                                             \
-    if ((mode) != 0) {                                                                             \
-      vts_set_error("dtype_mode %d not built into this library (0 = fp32 parity mode)", (int)(mode)); \
-      return VTS_ERR_UNSUPPORTED;                                                                  \
-    }                                                                                              \
+#define VTS_MODE_CHECK(mode)                                                                        \
+  do {                                                                                              \
+    if ((mode) != 0 && (mode) != 1) {                                                               \
+      vts_set_error("dtype_mode %d unknown (0 = f32 matrix cores, 1 = bf16x3 split GEMMs)", (int)(mode)); \
+      return VTS_ERR_UNSUPPORTED;                                                                   \
+    }                                                                                               \
   } while (0)
 
 #define VTS_RC(call)        \
@@ -101,7 +101,7 @@ size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
   return rec_ws_pack_bytes(H) + round256((size_t)(pad16(B) / 16) * 4 * H * sizeof(float));
 }
 size_t vts_lstm_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t F, int64_t H) {
-  const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T);
+  const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T, 0);   // mode 0 splits the most
   return round256(vts_gemm_slab_bytes((int)(4 * H), (int)F, ks)) + 256;
 }
 size_t vts_lstm_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H) {
@@ -126,7 +126,7 @@ int vts_lstm_inproj_fwd(const float* x, const float* w_ih, const float* b_ih, co
   VTS_RC(lstm_check(B, T, Cin, H));
   VTS_REQUIRE(x && w_ih && gates, "lstm_inproj_fwd: null pointer");
   VTS_REQUIRE(vts_aligned16(gates), "lstm_inproj_fwd: gates must be 16-byte aligned");
-  return vts_gemm_inproj(x, w_ih, b_ih, b_hh, gates, (int)B, (int)T, (int)Cin, (int)(4 * H),
+  return vts_gemm_inproj(x, w_ih, b_ih, b_hh, gates, (int)B, (int)T, (int)Cin, (int)(4 * H), dtype_mode,
                          reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -174,7 +174,7 @@ int vts_lstm_dgrad(const float* dgates, const float* w_ih, float* dx_t16, int64_
   VTS_REQUIRE(dgates && w_ih && dx_t16, "lstm_dgrad: null pointer");
   VTS_REQUIRE((Cin % 16) == 0, "lstm_dgrad: needs Cin %% 16 == 0 (got %ld)", (long)Cin);
   VTS_REQUIRE(vts_aligned16(dgates) && vts_aligned16(dx_t16) && vts_aligned16(w_ih), "lstm_dgrad: 16-byte alignment");
-  return vts_gemm_dgrad_t16(dgates, w_ih, dx_t16, (int)B, (int)T, (int)Cin, (int)(4 * H), 0,
+  return vts_gemm_dgrad_t16(dgates, w_ih, dx_t16, (int)B, (int)T, (int)Cin, (int)(4 * H), 0, dtype_mode,
                             reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -188,9 +188,9 @@ int vts_lstm_wgrad(const float* dgates, const float* x, int tshift, float* dw, i
   VTS_REQUIRE(vts_aligned16(dgates) && vts_aligned16(workspace), "lstm_wgrad: 16-byte alignment");
   VTS_REQUIRE(workspace_bytes >= vts_lstm_wgrad_workspace_bytes(B, T, F, H), "lstm_wgrad: workspace %zu B too small",
               workspace_bytes);
-  const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T);
+  const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T, dtype_mode);
   return vts_gemm_wgrad_t16(dgates, x, dw, reinterpret_cast<float*>(workspace), ks, (int)B, (int)T, (int)F, F,
-                            (int)(4 * H), tshift, accumulate, reinterpret_cast<hipStream_t>(stream));
+                            (int)(4 * H), tshift, accumulate, dtype_mode, reinterpret_cast<hipStream_t>(stream));
 }
 
 int vts_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
@@ -253,7 +253,7 @@ static LinWs lin_ws_layout(void* base, int64_t M, int64_t N, int64_t K) {
   char* p = reinterpret_cast<char*>(base);
   size_t off = 0;
   w.dpre = reinterpret_cast<float*>(p + off); off += round256((size_t)M * N * sizeof(float));
-  w.ksplit = vts_gemm_pick_ksplit((int)N, (int)K, M);
+  w.ksplit = vts_gemm_pick_ksplit((int)N, (int)K, M, 0);
   w.slabs = reinterpret_cast<float*>(p + off); off += round256(vts_gemm_slab_bytes((int)N, (int)K, w.ksplit));
   w.colpart = reinterpret_cast<float*>(p + off); off += round256((size_t)vts_ew_colsum_chunks((int)M) * N * sizeof(float));
   w.total = off;

@@ -5,6 +5,7 @@ sites.  All arithmetic runs in the HIP library; torch supplies device memory, st
 torch.distributed.  Importing works without a GPU; calling any op without one raises.
 """
 from . import _lib
+from .functional import get_mode, set_mode
 from .functional import (gaussian_elbo, gpd_elbo, layer_norm, linear, lstm, mixture_elbo,
                          reparameterize_gaussian, reparameterize_gpd, reparameterize_mixture)
 from .modules import (GPDVAE, LSTM, GaussianVAE, LayerNorm, Linear, MixtureVAE, build_model)
@@ -15,5 +16,5 @@ __all__ = [
     "LSTM", "Linear", "LayerNorm", "GaussianVAE", "GPDVAE", "MixtureVAE", "build_model",
     "lstm", "linear", "layer_norm", "reparameterize_gaussian", "reparameterize_gpd",
     "reparameterize_mixture", "gaussian_elbo", "gpd_elbo", "mixture_elbo",
-    "Adam", "FlatParameters", "train_step", "DataParallelTrainer", "shard_batch",
+    "set_mode", "get_mode", "Adam", "FlatParameters", "train_step", "DataParallelTrainer", "shard_batch",
 ]
