@@ -41,7 +41,7 @@ def test_argument_errors_are_reported_not_raised_in_c():
     lib = _lib.load()
     rc = lib.vts_lstm_inproj_fwd(None, None, None, None, None, 16, 4, 3, 48, 0, None)
     assert rc == 3 and b"hidden size 48" in lib.vts_last_error()
-    rc = lib.vts_linear_fwd(None, 4, None, None, None, 4, 4, 4, 0, None, 1.0, None, 1, None)
+    rc = lib.vts_linear_fwd(None, 4, None, None, None, 4, 4, 4, 0, None, 1.0, None, 7, None)
     assert rc == 3 and b"dtype_mode" in lib.vts_last_error()
     rc = lib.vts_adam_step(None, None, None, None, 10, 1, 1e-3, 0.9, 0.999, 1e-8, 1.0, None)
     assert rc == 1
