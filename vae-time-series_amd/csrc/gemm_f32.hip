@@ -406,7 +406,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK3 = 32;                 // k elements per main-loop iteration
 constexpr int ROWB = 80;                // LDS row pitch in bytes (32 bf16 + 16 B pad)
 constexpr int PLANE = 128 * ROWB;       // one plane (hi or lo) of one operand tile
-constexpr size_t GEMM3_LDS_BYTES = 4ul * PLANE;   // A hi, A lo, B hi, B lo
+#ifndef VTS_GEMM3_NSUB
+#define VTS_GEMM3_NSUB 1
+#endif
+#ifndef VTS_GEMM3_WPS
+#define VTS_GEMM3_WPS 3
+#endif
+constexpr int NSUB3 = VTS_GEMM3_NSUB;   // 32-deep k sub-chunks staged per barrier pair
+constexpr size_t GEMM3_LDS_BYTES = 4ul * PLANE * NSUB3;   // per sub-chunk: A hi, A lo, B hi, B lo
 
 // x -> (hi, lo) for two values at a time: one packed round-to-nearest conversion gives both hi
 // halves, two integer ops widen them back to fp32, one packed conversion rounds the residuals
@@ -533,13 +540,10 @@ template <int AK> struct OpKindA { static constexpr int v = (AK == A_ROW) ? 0 : 
 template <int BKIND> struct OpKindB { static constexpr int v = (BKIND == B_NK) ? 0 : 1; };
 
 template <int AK, int BKIND, int CK>
-__global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(const GemmParams P) {
-  extern __shared__ __attribute__((aligned(16))) char lds3[];   // [A hi | A lo | B hi | B lo]
-  char* a_hi = lds3;
-  char* a_lo = lds3 + PLANE;
-  char* b_hi = lds3 + 2 * PLANE;
-  char* b_lo = lds3 + 3 * PLANE;
+__global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) char lds3[];   // [sub][A hi | A lo | B hi | B lo]
   constexpr int OA = OpKindA<AK>::v, OB = OpKindB<BKIND>::v;
+  constexpr int BKL = BK3 * NSUB3;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -560,45 +564,59 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(const GemmParams P)
   if constexpr (AK == A_ROW) arow = a_row_base(P, m0, tid);
   if constexpr (BKIND == B_NK) brow = b_row_base(P, n0, tid);
 
-  float va[4][4], vb[4][4];
-  const int nk = (kend - kbeg + BK3 - 1) / BK3;
+  float va[NSUB3][4][4], vb[NSUB3][4][4];
+  auto stage_load = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < NSUB3; ++u) {
+      load3<OA>(P, true, arow, m0, k0 + u * BK3, kend, tid, va[u]);
+      load3<OB>(P, false, brow, n0, k0 + u * BK3, kend, tid, vb[u]);
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NSUB3; ++u) {
+      char* base = lds3 + u * 4 * PLANE;
+      store3<OA>(base, base + PLANE, tid, va[u]);
+      store3<OB>(base + 2 * PLANE, base + 3 * PLANE, tid, vb[u]);
+    }
+  };
+  const int nk = (kend - kbeg + BKL - 1) / BKL;
   if (nk > 0) {
-    load3<OA>(P, true, arow, m0, kbeg, kend, tid, va);
-    load3<OB>(P, false, brow, n0, kbeg, kend, tid, vb);
-    store3<OA>(a_hi, a_lo, tid, va);
-    store3<OB>(b_hi, b_lo, tid, vb);
+    stage_load(kbeg);
+    stage_store();
   }
   __syncthreads();
   const int a_off = (wm * 64 + r) * ROWB + g * 16;
   const int b_off = (wn * 64 + r) * ROWB + g * 16;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = (kt + 1) < nk;
-    if (more) {
-      load3<OA>(P, true, arow, m0, kbeg + (kt + 1) * BK3, kend, tid, va);
-      load3<OB>(P, false, brow, n0, kbeg + (kt + 1) * BK3, kend, tid, vb);
-    }
-    bf16x8 ah[4], al[4];
+    if (more) stage_load(kbeg + (kt + 1) * BKL);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + a_off + i * 16 * ROWB);
-      al[i] = *reinterpret_cast<const bf16x8*>(a_lo + a_off + i * 16 * ROWB);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + b_off + j * 16 * ROWB);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + b_off + j * 16 * ROWB);
+    for (int u = 0; u < NSUB3; ++u) {
+      const char* a_hi = lds3 + u * 4 * PLANE;
+      const char* a_lo = a_hi + PLANE;
+      const char* b_hi = a_hi + 2 * PLANE;
+      const char* b_lo = a_hi + 3 * PLANE;
+      bf16x8 ah[4], al[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + a_off + i * 16 * ROWB);
+        al[i] = *reinterpret_cast<const bf16x8*>(a_lo + a_off + i * 16 * ROWB);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + b_off + j * 16 * ROWB);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + b_off + j * 16 * ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
       }
     }
     __syncthreads();           // every wave is done reading this k chunk
-    if (more) {
-      store3<OA>(a_hi, a_lo, tid, va);
-      store3<OB>(b_hi, b_lo, tid, vb);
-    }
+    if (more) stage_store();
     __syncthreads();
   }
   epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane);
@@ -621,6 +639,18 @@ template <int AK, int BKIND, int CK>
 int launch3(const GemmParams& P, hipStream_t stream) {
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
+  if (GEMM3_LDS_BYTES > 64 * 1024) {
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<AK, BKIND, CK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
+      if (e != hipSuccess) {
+        vts_set_error("gemm_bf16x3: cannot reserve %zu B of LDS: %s", GEMM3_LDS_BYTES, hipGetErrorString(e));
+        return VTS_ERR_HIP;
+      }
+      attr_set = true;
+    }
+  }
   hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, BKIND, CK>), dim3((unsigned)nwg), dim3(256), GEMM3_LDS_BYTES, stream, P);
   VTS_CHECK_LAUNCH("gemm_bf16x3");
   return VTS_OK;
@@ -689,7 +719,7 @@ static int finish_split(GemmParams P, float* Cfinal, long ldc, int accumulate, h
 static void set_split(GemmParams& P, int ksplit) {
   P.ksplit = ksplit < 1 ? 1 : ksplit;
   long chunk = (P.K + P.ksplit - 1) / P.ksplit;
-  chunk = (chunk + 31) / 32 * 32;
+  chunk = (chunk + 63) / 64 * 64;
   P.kchunk = (int)chunk;
   P.ksplit = (int)((P.K + chunk - 1) / chunk);
   if (P.ksplit < 1) P.ksplit = 1;

@@ -28,7 +28,6 @@ struct RecCfg {
   static constexpr int JPW = JT / NW;               // hidden tiles per wave
   static constexpr int KQ_F = H / 16;               // k-quads (16 k each) in the forward product
   static constexpr int KQ_B = (4 * H) / 16;         // k-quads in the backward product
-  static constexpr int LDH = H + 4;                 // LDS row stride of the h tile
   static constexpr int LDA = 4 * H + 4;             // LDS row stride of the dA tile
 };
 
@@ -105,7 +104,15 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
     float* __restrict__ clast, const float* __restrict__ Wp, int B, int T) {
   using C = RecCfg<H>;
   constexpr int NT = C::JPW * 4;
-  __shared__ __attribute__((aligned(16))) float hl[2][16 * C::LDH];
+  // LDS: the double-buffered h tile, [2][16][H] floats with the 16-byte column index XOR-ed with
+  // the row (conflict-free fragment reads without padding: the tile is a power of two and the
+  // rest of the 160 KiB holds W_hh), then NLB resident W_hh k-quads in fragment order.
+  constexpr int NLB = C::KQ_F / 8;                  // k-quads of W_hh kept in LDS (2 at H = 256)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hl0 = smem;
+  f32x4* wlds = reinterpret_cast<f32x4*>(smem + 2 * 16 * H);   // [NLB][NT][NW*64]
+  constexpr int SWZ = (H / 4 < 16 ? H / 4 : 16) - 1;
+  auto hidx = [](int row, int col) { return row * H + ((((col >> 2) ^ (row & SWZ)) << 2) | (col & 3)); };
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -131,6 +138,18 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
         gv[jl * 4 + q] = ld_stream(Gt + (long)(q * C::JT + wave * C::JPW + jl) * 256);
   };
 
+  // k-quad 8*n + 7 lives in LDS slot n (each wave keeps and re-reads only its own fragments)
+  auto load_w_lds = [&](f32x4 (&w)[NT], int slot) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) w[i] = wlds[(slot * NT + i) * (C::NW * 64) + tid];
+  };
+  if constexpr (NLB > 0) {
+#pragma unroll 1
+    for (int n = 0; n < NLB; ++n)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wlds[(n * NT + i) * (C::NW * 64) + tid] = Wv[((8 * n + 7) * NT + i) * 64];
+  }
+
   f32x4 gnext[NT];
   load_g(gnext, 0);
 
@@ -146,14 +165,15 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
 
   for (int t = 0; t < T; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
+    float* hcur = hl0 + cur * (16 * H);
+    float* hnxt = hl0 + nxt * (16 * H);
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = gnext[i];
     if (t + 1 < T) load_g(gnext, t + 1);
 
     if (t > 0) {
-      const float* hrow = &hl[cur][r * C::LDH + 4 * g];
-      auto lds_a = [&](int kq) { return *reinterpret_cast<const f32x4*>(hrow + 16 * kq); };
+      auto lds_a = [&](int kq) { return *reinterpret_cast<const f32x4*>(&hcur[hidx(r, 16 * kq + 4 * g)]); };
       auto mma_a = [&](const f32x4 (&w)[NT], const f32x4 a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -177,7 +197,8 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
         };
 #pragma unroll 1
         for (int kq = 0; kq < C::KQ_F; kq += 4) {
-          load_w(w3, kq + 3);
+          if (NLB > 0 && (kq & 4)) load_w_lds(w3, kq >> 3);   // k-quads 7, 15: LDS-resident
+          else load_w(w3, kq + 3);
           block(w0, kq);
           load_w(w0, (kq + 4) & (C::KQ_F - 1));
           block(w1, kq + 1);
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
         go[reg] = fast_sigmoid(acc[jl * 4 + 3][reg]);
         c[jl][reg] = gf[reg] * c[jl][reg] + gi[reg] * gg[reg];
         hv[reg] = go[reg] * fast_tanh(c[jl][reg]);
-        hl[nxt][(4 * g + reg) * C::LDH + jt * 16 + r] = hv[reg];
+        hnxt[hidx(4 * g + reg, jt * 16 + r)] = hv[reg];
       }
       st_stream(Gt + (long)(0 * C::JT + jt) * 256, gi);
       st_stream(Gt + (long)(1 * C::JT + jt) * 256, gf);
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
       const int row = idx / (H / 4), c4 = idx % (H / 4);
       const int b = b0 + row;
       if (b < B) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&hl[nxt][row * C::LDH + 4 * c4]);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&hnxt[hidx(row, 4 * c4)]);
         st_stream(hseq + ((long)b * T + t) * H + 4 * c4, v);
         if (hlast != nullptr && t == T - 1) *reinterpret_cast<f32x4*>(hlast + (long)b * H + 4 * c4) = v;
       }
@@ -465,8 +486,19 @@ int run_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, cons
   hipLaunchKernelGGL(pack_whh_fwd_kernel<H>, dim3(vts_cdiv(4 * H * H, 256)), dim3(256), 0, stream, W_hh, Wp);
   VTS_CHECK_LAUNCH("pack_whh_fwd");
   const int nbt = (B + 15) / 16;
-  hipLaunchKernelGGL(lstm_rec_fwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), 0, stream, G, cseq, hseq, hlast, clast, Wp,
-                     B, T);
+  const size_t lds = (2ul * 16 * H + (size_t)(C::KQ_F / 8) * C::JPW * 4 * C::NW * 64 * 4) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_fwd_kernel<H>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      vts_set_error("lstm_rec_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      return VTS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_rec_fwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), lds, stream, G, cseq, hseq, hlast, clast,
+                     Wp, B, T);
   VTS_CHECK_LAUNCH("lstm_rec_fwd");
   return VTS_OK;
 }
