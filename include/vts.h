@@ -11,8 +11,11 @@
  *    stream ordering and can be made from any host thread;
  *  - return 0 on success, otherwise VTS_ERR_* with a message in a thread-local buffer
  *    (vts_last_error()); no C++ exception crosses the boundary;
- *  - `dtype_mode`: 0 = fp32 arithmetic on the f32 matrix cores (parity mode).  Other values are
- *    rejected by this build.
+ *  - `dtype_mode`: 0 = fp32 operands on the f32 matrix cores (v_mfma_f32_16x16x4_f32);
+ *    1 = "bf16x3": each fp32 operand is split into a bf16 head and a bf16 tail while it is staged,
+ *    the product is head*head + head*tail + tail*head on the bf16 matrix cores with fp32
+ *    accumulation (error ~2^-16 per product, inside the 1e-4 parity bound).  The recurrent
+ *    kernels always compute in fp32.  Other values are rejected.
  *
  * Layouts
  *  - sequences are batch-first row-major [B, T, F] exactly as the reference feeds nn.LSTM;
@@ -172,6 +175,37 @@ int vts_elbo_bwd(int family, const float* recon, const float* y, const float* me
                  const float* grad_out, float threshold, float* drecon, float* dmean, float* dlogvar,
                  float* dscale, float* dshape, float* dpi, int64_t B, int64_t fs, int64_t L,
                  vts_stream_t stream);
+
+/* ---- Sampling fused with the KL sums, and the loss built from those sums ----
+ * One training step reads mean/logvar/scale/shape twice in the reference: once to sample z
+ * (mixture-vae-DE.py:94-107) and once for the KL terms of the loss (:123-127).  These entry points
+ * do both in one pass over HBM and one pass back:
+ *   vts_reparam_kl_fwd : z as vts_reparam_fwd, plus klpart[nblk][2] = per-block partial sums of
+ *                        {1+lv-mu^2-e^lv,  log scale + log(1+shape*threshold/scale)},
+ *                        nblk = vts_reparam_kl_blocks(B, L).  A mixture row reads only the noise of
+ *                        the family it selected.
+ *   vts_elbo_recon_fwd : the loss of vts_elbo_fwd from recon, y and klpart (same state[16] layout).
+ *   vts_elbo_recon_bwd : drecon, dpi and dklpart[nblk][2] = d loss / d klpart.
+ *   vts_reparam_kl_bwd : sampling gradient (from dz, NULL = 0) + KL gradient (from dklpart,
+ *                        NULL = 0) written once to dmean/dlogvar/dscale/dshape.
+ * Results equal vts_reparam_* + vts_elbo_* up to the order of the fp32 partial sums. */
+int64_t vts_reparam_kl_blocks(int64_t B, int64_t L);
+int vts_reparam_kl_fwd(int family, const float* mean, const float* logvar, const float* scale,
+                       const float* shape, const float* eps, const float* u, const float* choice,
+                       const float* pi, float threshold, float* z, float* klpart, int64_t B, int64_t L,
+                       vts_stream_t stream);
+int vts_reparam_kl_bwd(int family, const float* dz, const float* dklpart, const float* mean,
+                       const float* logvar, const float* scale, const float* shape, const float* eps,
+                       const float* u, const float* choice, const float* pi, float threshold,
+                       float* dmean, float* dlogvar, float* dscale, float* dshape, int64_t B, int64_t L,
+                       vts_stream_t stream);
+int vts_elbo_recon_fwd(int family, const float* recon, const float* y, const float* klpart,
+                       int64_t nklpart, const float* pi, float threshold, float beta, float* state,
+                       void* workspace, size_t workspace_bytes, int64_t B, int64_t fs, int64_t L,
+                       vts_stream_t stream);
+int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const float* state,
+                       const float* grad_out, float threshold, float* drecon, float* dklpart,
+                       int64_t nklpart, float* dpi, int64_t B, int64_t fs, vts_stream_t stream);
 
 /* ---- Adam (torch.optim.Adam defaults, no weight decay) over one flat buffer ----
  * gaussian-lstm-DE.py:142,154 ; gpd-lstm-DE.py:88,104 ; mixture-vae-DE.py:147,163.

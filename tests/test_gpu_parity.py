@@ -317,6 +317,72 @@ def test_reparam_and_elbo_ops(B, Ld):
     assert abs(lp.item() - R.loss_gpd(recon, y, scale, shape).item()) < 1e-5 * abs(lp.item())
 
 
+@pytest.mark.parametrize("family", ["gaussian", "gpd", "mixture"])
+@pytest.mark.parametrize("B,Ld", [(16, 32), (4096, 32), (7, 8), (33, 5), (70000, 32)])
+def test_fused_sampling_and_kl_matches_separate_kernels(family, B, Ld):
+    """vts_reparam_kl_* + vts_elbo_recon_* (one pass over the latent parameters each way) against
+    vts_reparam_* + vts_elbo_* on the same inputs: z bit-equal (same expressions), loss 1e-6
+    (partial sums in a different order), gradients 1e-5 L2-relative.  (33, 5) takes the 4-byte
+    path, (70000, 32) makes blocks own several chunks."""
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 7 + Ld)
+    mean = torch.randn(B, Ld, generator=g)
+    logvar = torch.randn(B, Ld, generator=g) * 0.5
+    scale = torch.exp(torch.randn(B, Ld, generator=g) * 0.3)
+    shape = torch.clamp(torch.randn(B, Ld, generator=g) * 0.2, min=1e-6)
+    eps, u = torch.randn(B, Ld, generator=g), torch.rand(B, Ld, generator=g)
+    choice = torch.rand(B, generator=g)
+    recon, y = torch.randn(B, 1, generator=g), torch.randn(B, 1, generator=g)
+    dz = torch.randn(B, Ld, generator=g).to(dev)
+    thr = 0.5
+
+    def run(fused):
+        m, lv, sc, sh, rc = [t.to(dev).requires_grad_(True) for t in (mean, logvar, scale, shape, recon)]
+        pi = torch.tensor([0.3, 0.1], device=dev, requires_grad=True)
+        e, uu, ch, yy = eps.to(dev), u.to(dev), choice.to(dev), y.to(dev)
+        if family == "gaussian":
+            out = vts.reparameterize_gaussian(m, lv, e, with_kl=fused)
+            z, kl = out if fused else (out, None)
+            loss = vts.gaussian_elbo(rc, yy, m, lv, 0.01, kl=kl)
+            leaves = [m, lv, rc]
+        elif family == "gpd":
+            out = vts.reparameterize_gpd(sc, sh, None, uu, kl_threshold=thr if fused else None)
+            z, kl = out if fused else (out, None)
+            loss = vts.gpd_elbo(rc, yy, sc, sh, thr, 0.01, kl=kl)
+            leaves = [sc, sh, rc]
+        else:
+            out = vts.reparameterize_mixture(m, lv, sc, sh, pi, ch, e, uu, kl_threshold=thr if fused else None)
+            z, kl = out if fused else (out, None)
+            loss = vts.mixture_elbo(rc, yy, m, lv, sc, sh, pi, thr, 0.01, kl=kl)
+            leaves = [m, lv, sc, sh, rc, pi]
+        ((z * dz).sum() + loss * 1.7).backward()
+        return z.detach(), loss.detach(), [t.grad for t in leaves]
+
+    z0, l0, g0 = run(False)
+    z1, l1, g1 = run(True)
+    assert torch.equal(z0, z1)
+    assert abs(l0.item() - l1.item()) <= 1e-6 * abs(l0.item())
+    for a, b in zip(g0, g1):
+        assert l2_rel(b, a) < 1e-5
+
+
+def test_fused_kl_sums_are_used_only_for_their_own_tensors():
+    """KLSums handed to an elbo call with other tensors or another threshold must be ignored."""
+    import vts
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    sc = torch.exp(torch.randn(64, 32, generator=g) * 0.3).to(dev)
+    sh = (torch.rand(64, 32, generator=g) * 0.3 + 0.05).to(dev)
+    u = torch.rand(64, 32, generator=g).to(dev)
+    rc, y = torch.randn(64, 1, generator=g).to(dev), torch.randn(64, 1, generator=g).to(dev)
+    _, kl = vts.reparameterize_gpd(sc, sh, None, u, kl_threshold=0.5)
+    ref = vts.gpd_elbo(rc, y, sc, sh, 2.0, 0.01)
+    assert vts.gpd_elbo(rc, y, sc, sh, 2.0, 0.01, kl=kl).item() == ref.item()          # other threshold
+    sc2 = sc * 1.5
+    assert vts.gpd_elbo(rc, y, sc2, sh, 0.5, 0.01, kl=kl).item() == vts.gpd_elbo(rc, y, sc2, sh, 0.5, 0.01).item()
+
+
 def test_gpd_sampler_is_bit_exact_at_the_clamp():
     """shape == 1e-6: z = scale/1e-6 * ((1-u)**(-1e-6) - 1) is quantised in steps of
     ~0.119*scale; only a correctly rounded pow reproduces the reference's values."""

@@ -2,6 +2,8 @@
 // the three ELBO losses with their gradients, LayerNorm, activation gradients, column sums and
 // the Adam update.  All fp32, 16-byte accesses where the shapes allow, wave64 shuffle reductions.
 #include "vts_common.h"
+#include "vts_gpd_pow.h"
+#include <initializer_list>
 
 namespace {
 
@@ -40,10 +42,8 @@ __device__ __forceinline__ float softmax0(const float* pi) {
 // scale / shape * ((1 - u) ** (-shape) - 1).  The power is evaluated in fp64 and rounded once:
 // near the shape clamp (1e-6) the result sits a few ulps above 1 and the subtraction that
 // follows amplifies any last-bit difference by ~1e6, so the power must be correctly rounded
-// (torch's CPU fp32 pow is, in that regime).
-__device__ __forceinline__ float gpd_pow(float base, float expo) {
-  return (float)pow((double)base, (double)expo);
-}
+// (torch's CPU fp32 pow is, in that regime); vts_gpd_pow.h holds the short fp64 evaluation.
+__device__ __forceinline__ float gpd_pow(float base, float expo) { return vts_gpd_pow(base, expo); }
 
 // mode 0: z = mean + eps*exp(0.5*logvar)
 // mode 1: z = GPD sample
@@ -114,6 +114,136 @@ __global__ void reparam_bwd_kernel(int mode, const float* __restrict__ dz, const
   }
 }
 
+// ----------------------------------------------------------- fused sampling + KL (one HBM pass)
+// Forward: z as reparam_fwd_kernel computes it, plus this block's share of the two KL sums
+//   part[blk][0] = sum 1 + lv - mu^2 - e^lv      part[blk][1] = sum log(scale) + log(1 + shape*thr/scale)
+// so mean / logvar / scale / shape are read once for both.  Backward: the sampling gradient
+// (from dz) and the KL gradient (from d loss / d part) in one pass, written once.
+// Elements are owned in chunks of 1024: chunk c belongs to block c % gridDim.x in both kernels and
+// for both access widths, so dpart[blk] is the coefficient of exactly the elements summed into
+// part[blk].  V = 4: 16-byte accesses (L % 4 == 0, so the four elements share a row).
+// In the mixture a row reads only the noise of the family it selected (eps or u).
+template <int V> struct VecT { using type = float; };
+template <> struct VecT<4> { using type = f32x4; };
+
+template <int V>
+__device__ __forceinline__ void ld_vec(float (&d)[V], const float* p) {
+  if constexpr (V == 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  } else {
+    d[0] = *p;
+  }
+}
+template <int V>
+__device__ __forceinline__ void st_vec(float* p, const float (&d)[V]) {
+  if constexpr (V == 4) *reinterpret_cast<f32x4*>(p) = f32x4{d[0], d[1], d[2], d[3]};
+  else *p = d[0];
+}
+
+template <int MODE, int V>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
+    const float* __restrict__ mean, const float* __restrict__ logvar, const float* __restrict__ scale,
+    const float* __restrict__ shape, const float* __restrict__ eps, const float* __restrict__ u,
+    const float* __restrict__ choice, const float* __restrict__ pi, float thr, float* __restrict__ z,
+    float* __restrict__ part, long n, int L) {
+  __shared__ float smem[8];
+  float p0 = 0.f;
+  if (MODE == 2) p0 = softmax0(pi);
+  float s[2] = {0.f, 0.f};
+  const long nchunk = (n + 1023) >> 10;
+  for (long c = blockIdx.x; c < nchunk; c += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 4 / V; ++j) {
+      const long e = (c << 10) + (V == 4 ? threadIdx.x * 4 : j * 256 + threadIdx.x);
+      if (e >= n) continue;
+      bool gauss = (MODE == 0);
+      if (MODE == 2) gauss = choice[e / L] < p0;
+      float mu[V], lv[V], sc[V], sh[V], nz[V], out[V];
+      if (MODE != 1) { ld_vec<V>(mu, mean + e); ld_vec<V>(lv, logvar + e); }
+      if (MODE != 0) { ld_vec<V>(sc, scale + e); ld_vec<V>(sh, shape + e); }
+      ld_vec<V>(nz, (gauss ? eps : u) + e);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        if (MODE != 1) s[0] += 1.f + lv[k] - mu[k] * mu[k] - expf(lv[k]);
+        if (MODE != 0) s[1] += logf(sc[k]) + logf(1.f + sh[k] * thr / sc[k]);
+        if (gauss) {
+          out[k] = mu[k] + nz[k] * expf(0.5f * lv[k]);
+        } else {
+          const float p = gpd_pow(1.0f - nz[k], -sh[k]);
+          out[k] = (sc[k] / sh[k]) * (p - 1.0f);
+        }
+      }
+      st_vec<V>(z + e, out);
+    }
+  }
+  block_sum<2>(s, smem);
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = s[0]; part[blockIdx.x * 2 + 1] = s[1]; }
+}
+
+template <int MODE, int V>
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ dpart, const float* __restrict__ mean,
+    const float* __restrict__ logvar, const float* __restrict__ scale, const float* __restrict__ shape,
+    const float* __restrict__ eps, const float* __restrict__ u, const float* __restrict__ choice,
+    const float* __restrict__ pi, float thr, float* __restrict__ dmean, float* __restrict__ dlogvar,
+    float* __restrict__ dscale, float* __restrict__ dshape, long n, int L) {
+  float p0 = 0.f;
+  if (MODE == 2) p0 = softmax0(pi);
+  const float c_klg = dpart ? dpart[blockIdx.x * 2] : 0.f;
+  const float c_klp = dpart ? dpart[blockIdx.x * 2 + 1] : 0.f;
+  const long nchunk = (n + 1023) >> 10;
+  for (long c = blockIdx.x; c < nchunk; c += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 4 / V; ++j) {
+      const long e = (c << 10) + (V == 4 ? threadIdx.x * 4 : j * 256 + threadIdx.x);
+      if (e >= n) continue;
+      bool gauss = (MODE == 0);
+      if (MODE == 2) gauss = choice[e / L] < p0;
+      float d[V], mu[V], lv[V], sc[V], sh[V], nz[V];
+      if (dz) {
+        ld_vec<V>(d, dz + e);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) d[k] = 0.f;
+      }
+      if (MODE != 1) { ld_vec<V>(mu, mean + e); ld_vec<V>(lv, logvar + e); }
+      if (MODE != 0) { ld_vec<V>(sc, scale + e); ld_vec<V>(sh, shape + e); }
+      ld_vec<V>(nz, (gauss ? eps : u) + e);
+      float dm[V], dl[V], dsc[V], dsh[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        if (MODE != 1) {
+          // KL part as elbo_grads_kernel, sampling part as reparam_bwd_kernel
+          dm[k] = c_klg * (-2.f * mu[k]);
+          dl[k] = c_klg * (1.f - expf(lv[k]));
+          if (gauss) {
+            dm[k] += d[k];
+            dl[k] += d[k] * nz[k] * expf(0.5f * lv[k]) * 0.5f;
+          }
+        }
+        if (MODE != 0) {
+          const float w = 1.f + sh[k] * thr / sc[k];
+          dsc[k] = c_klp * (1.f / sc[k] - (sh[k] * thr / (sc[k] * sc[k])) / w);
+          dsh[k] = c_klp * ((thr / sc[k]) / w);
+          if (!gauss) {
+            const float base = 1.0f - nz[k];
+            const float p = gpd_pow(base, -sh[k]);
+            const float a = sc[k] / sh[k];
+            const float q = p - 1.0f;
+            const float da = d[k] * q, dq = d[k] * a;
+            dsc[k] += da / sh[k];
+            const float de = dq * (p * logf(base));
+            dsh[k] += -da * (a / sh[k]) - de;
+          }
+        }
+      }
+      if (MODE != 1) { st_vec<V>(dmean + e, dm); st_vec<V>(dlogvar + e, dl); }
+      if (MODE != 0) { st_vec<V>(dscale + e, dsc); st_vec<V>(dshape + e, dsh); }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------- ELBO
 // kind 0 gaussian, 1 gpd, 2 mixture.  Partial sums per block, 5 slots:
 //   0: sum (recon-y)^2          1: same over |y| <= thr      2: count |y| <= thr
@@ -153,14 +283,19 @@ __global__ __launch_bounds__(256) void elbo_partials_kernel(
 // out[0] = loss; out[1..7] = coefficients used by elbo_grads_kernel; out[8], out[9] = d loss / d pi_params
 //   1: c_all   d loss / d recon = c_all * (recon-y) (+ c_norm * (recon-y) on normal rows)
 //   2: c_norm  3: c_klg (multiplies d/dx of sum(1+lv-mu^2-e^lv))  4: c_klp
+// klpart / nkl: optional [nkl][2] partial sums of slots 3 and 4 produced by reparam_kl_fwd_kernel.
 __global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, int nparts,
-                                     const float* __restrict__ pi, float beta, long B, long nrec, long nlat,
-                                     float* __restrict__ out) {
+                                     const float* __restrict__ klpart, int nkl, const float* __restrict__ pi,
+                                     float beta, long B, long nrec, long nlat, float* __restrict__ out) {
   __shared__ float smem[20];
   float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int p = threadIdx.x; p < nparts; p += blockDim.x)
 #pragma unroll
     for (int i = 0; i < 5; ++i) s[i] += part[(long)p * 5 + i];
+  for (int p = threadIdx.x; p < nkl; p += blockDim.x) {
+    s[3] += klpart[2 * p];
+    s[4] += klpart[2 * p + 1];
+  }
   block_sum<5>(s, smem);
   if (threadIdx.x != 0) return;
   const float R = s[0] / (float)nrec;
@@ -204,12 +339,15 @@ __global__ void elbo_grads_kernel(int kind, const float* __restrict__ recon, con
                                   const float* __restrict__ coef, const float* __restrict__ gout, float thr,
                                   long nrec, long nlat, float* __restrict__ drecon, float* __restrict__ dmean,
                                   float* __restrict__ dlogvar, float* __restrict__ dscale,
-                                  float* __restrict__ dshape, float* __restrict__ dpi) {
+                                  float* __restrict__ dshape, float* __restrict__ dpi,
+                                  float* __restrict__ dklpart, int nkl) {
   const float go = gout ? gout[0] : 1.f;
   const float c_all = coef[1] * go, c_norm = coef[2] * go, c_klg = coef[3] * go, c_klp = coef[4] * go;
   const long stride = (long)gridDim.x * blockDim.x;
   const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (start == 0 && kind == 2 && dpi) { dpi[0] = coef[8] * go; dpi[1] = coef[9] * go; }
+  // d loss / d (KL partial sums): the same two coefficients for every block of the fused kernel
+  for (long i = start; i < nkl; i += stride) { dklpart[2 * i] = c_klg; dklpart[2 * i + 1] = c_klp; }
   for (long i = start; i < nrec; i += stride) {
     const float yv = y[i];
     const float d = recon[i] - yv;
@@ -411,9 +549,102 @@ int vts_ew_elbo_fwd(int kind, const float* recon, const float* y, const float* m
   hipLaunchKernelGGL(elbo_partials_kernel, dim3(blocks), dim3(256), 0, st, kind, recon, y, mean, logvar, scale,
                      shape, thr, nrec, nlat, part);
   VTS_CHECK_LAUNCH("elbo_partials");
-  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, pi, beta, B, nrec, nlat,
-                     out10);
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, (const float*)nullptr, 0,
+                     pi, beta, B, nrec, nlat, out10);
   VTS_CHECK_LAUNCH("elbo_finalize");
+  return VTS_OK;
+}
+
+int vts_ew_reparam_kl_blocks(long B, int L) {
+  long c = (B * L + 1023) / 1024;
+  if (c > 2048) c = 2048;
+  return c < 1 ? 1 : (int)c;
+}
+
+namespace {
+template <int V>
+int reparam_kl_fwd_v(int mode, const float* mean, const float* logvar, const float* scale, const float* shape,
+                     const float* eps, const float* u, const float* choice, const float* pi, float thr, float* z,
+                     float* part, long n, int L, int blocks, hipStream_t st) {
+#define VTS_RKF(M)                                                                                                 \
+  hipLaunchKernelGGL((reparam_kl_fwd_kernel<M, V>), dim3(blocks), dim3(256), 0, st, mean, logvar, scale, shape, eps, \
+                     u, choice, pi, thr, z, part, n, L)
+  if (mode == 0) VTS_RKF(0);
+  else if (mode == 1) VTS_RKF(1);
+  else VTS_RKF(2);
+#undef VTS_RKF
+  VTS_CHECK_LAUNCH("reparam_kl_fwd");
+  return VTS_OK;
+}
+template <int V>
+int reparam_kl_bwd_v(int mode, const float* dz, const float* dpart, const float* mean, const float* logvar,
+                     const float* scale, const float* shape, const float* eps, const float* u, const float* choice,
+                     const float* pi, float thr, float* dmean, float* dlogvar, float* dscale, float* dshape, long n,
+                     int L, int blocks, hipStream_t st) {
+#define VTS_RKB(M)                                                                                              \
+  hipLaunchKernelGGL((reparam_kl_bwd_kernel<M, V>), dim3(blocks), dim3(256), 0, st, dz, dpart, mean, logvar, scale, \
+                     shape, eps, u, choice, pi, thr, dmean, dlogvar, dscale, dshape, n, L)
+  if (mode == 0) VTS_RKB(0);
+  else if (mode == 1) VTS_RKB(1);
+  else VTS_RKB(2);
+#undef VTS_RKB
+  VTS_CHECK_LAUNCH("reparam_kl_bwd");
+  return VTS_OK;
+}
+inline bool aligned16(std::initializer_list<const void*> ps) {
+  for (const void* p : ps)
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
+  return true;
+}
+}  // namespace
+
+int vts_ew_reparam_kl_fwd(int mode, const float* mean, const float* logvar, const float* scale, const float* shape,
+                          const float* eps, const float* u, const float* choice, const float* pi, float thr, float* z,
+                          float* part, long B, int L, hipStream_t st) {
+  const long n = B * L;
+  const int blocks = vts_ew_reparam_kl_blocks(B, L);
+  const bool v4 = (L % 4 == 0) && aligned16({mean, logvar, scale, shape, eps, u, z});
+  return v4 ? reparam_kl_fwd_v<4>(mode, mean, logvar, scale, shape, eps, u, choice, pi, thr, z, part, n, L, blocks, st)
+            : reparam_kl_fwd_v<1>(mode, mean, logvar, scale, shape, eps, u, choice, pi, thr, z, part, n, L, blocks, st);
+}
+
+int vts_ew_reparam_kl_bwd(int mode, const float* dz, const float* dpart, const float* mean, const float* logvar,
+                          const float* scale, const float* shape, const float* eps, const float* u,
+                          const float* choice, const float* pi, float thr, float* dmean, float* dlogvar,
+                          float* dscale, float* dshape, long B, int L, hipStream_t st) {
+  const long n = B * L;
+  const int blocks = vts_ew_reparam_kl_blocks(B, L);
+  const bool v4 = (L % 4 == 0) && aligned16({dz, mean, logvar, scale, shape, eps, u, dmean, dlogvar, dscale, dshape});
+  return v4 ? reparam_kl_bwd_v<4>(mode, dz, dpart, mean, logvar, scale, shape, eps, u, choice, pi, thr, dmean,
+                                  dlogvar, dscale, dshape, n, L, blocks, st)
+            : reparam_kl_bwd_v<1>(mode, dz, dpart, mean, logvar, scale, shape, eps, u, choice, pi, thr, dmean,
+                                  dlogvar, dscale, dshape, n, L, blocks, st);
+}
+
+// Loss from the reconstruction pair and KL partial sums already produced by vts_ew_reparam_kl_fwd.
+int vts_ew_elbo_recon_fwd(int kind, const float* recon, const float* y, const float* klpart, int nkl,
+                          const float* pi, float thr, float beta, long B, int fs, int L, float* part, float* out10,
+                          hipStream_t st) {
+  const long nrec = B * fs, nlat = B * L;
+  const int blocks = vts_ew_elbo_blocks(nrec, 0);
+  hipLaunchKernelGGL(elbo_partials_kernel, dim3(blocks), dim3(256), 0, st, kind, recon, y, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, thr, nrec, 0L, part);
+  VTS_CHECK_LAUNCH("elbo_partials");
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, klpart, nkl, pi, beta, B,
+                     nrec, nlat, out10);
+  VTS_CHECK_LAUNCH("elbo_finalize");
+  return VTS_OK;
+}
+
+int vts_ew_elbo_recon_bwd(int kind, const float* recon, const float* y, const float* coef, const float* gout,
+                          float thr, long B, int fs, float* drecon, float* dklpart, int nkl, float* dpi,
+                          hipStream_t st) {
+  const long nrec = B * fs;
+  const long m = nrec > nkl ? nrec : (long)nkl;
+  hipLaunchKernelGGL(elbo_grads_kernel, dim3(grid_for(m)), dim3(256), 0, st, kind, recon, y, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, coef, gout, thr, nrec, 0L,
+                     drecon, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, dpi, dklpart, nkl);
+  VTS_CHECK_LAUNCH("elbo_grads");
   return VTS_OK;
 }
 
@@ -424,7 +655,7 @@ int vts_ew_elbo_bwd(int kind, const float* recon, const float* y, const float* m
   const long nrec = B * fs, nlat = B * L;
   hipLaunchKernelGGL(elbo_grads_kernel, dim3(grid_for(nlat > nrec ? nlat : nrec)), dim3(256), 0, st, kind, recon, y,
                      mean, logvar, scale, shape, coef, gout, thr, nrec, nlat, drecon, dmean, dlogvar, dscale, dshape,
-                     dpi);
+                     dpi, (float*)nullptr, 0);
   VTS_CHECK_LAUNCH("elbo_grads");
   return VTS_OK;
 }

@@ -33,6 +33,20 @@ int vts_ew_reparam_fwd(int mode, const float* mean, const float* logvar, const f
 int vts_ew_reparam_bwd(int mode, const float* dz, const float* logvar, const float* scale, const float* shape,
                        const float* eps, const float* u, const float* choice, const float* pi, float* dmean,
                        float* dlogvar, float* dscale, float* dshape, long B, int L, hipStream_t st);
+int vts_ew_reparam_kl_blocks(long B, int L);
+int vts_ew_reparam_kl_fwd(int mode, const float* mean, const float* logvar, const float* scale, const float* shape,
+                          const float* eps, const float* u, const float* choice, const float* pi, float thr, float* z,
+                          float* part, long B, int L, hipStream_t st);
+int vts_ew_reparam_kl_bwd(int mode, const float* dz, const float* dpart, const float* mean, const float* logvar,
+                          const float* scale, const float* shape, const float* eps, const float* u,
+                          const float* choice, const float* pi, float thr, float* dmean, float* dlogvar,
+                          float* dscale, float* dshape, long B, int L, hipStream_t st);
+int vts_ew_elbo_recon_fwd(int kind, const float* recon, const float* y, const float* klpart, int nkl,
+                          const float* pi, float thr, float beta, long B, int fs, int L, float* part, float* out10,
+                          hipStream_t st);
+int vts_ew_elbo_recon_bwd(int kind, const float* recon, const float* y, const float* coef, const float* gout,
+                          float thr, long B, int fs, float* drecon, float* dklpart, int nkl, float* dpi,
+                          hipStream_t st);
 int vts_ew_elbo_blocks(long nrec, long nlat);
 int vts_ew_elbo_fwd(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
                     const float* scale, const float* shape, const float* pi, float thr, float beta, long B, int fs,
@@ -367,6 +381,60 @@ int vts_elbo_bwd(int family, const float* recon, const float* y, const float* me
   VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape && dscale && dshape), "elbo_bwd: gpd buffers missing");
   return vts_ew_elbo_bwd(family, recon, y, mean, logvar, scale, shape, state, grad_out, threshold, B, (int)fs, (int)L,
                          drecon, dmean, dlogvar, dscale, dshape, dpi, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------- fused sampling + KL, loss from sums
+int64_t vts_reparam_kl_blocks(int64_t B, int64_t L) {
+  if (B <= 0 || L <= 0) return 0;
+  return vts_ew_reparam_kl_blocks(B, (int)L);
+}
+
+int vts_reparam_kl_fwd(int family, const float* mean, const float* logvar, const float* scale, const float* shape,
+                       const float* eps, const float* u, const float* choice, const float* pi, float threshold,
+                       float* z, float* klpart, int64_t B, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && z && klpart && B > 0 && L > 0, "reparam_kl_fwd: bad arguments");
+  VTS_REQUIRE(family == VTS_GPD || (mean && logvar && eps), "reparam_kl_fwd: gaussian inputs missing");
+  VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape && u), "reparam_kl_fwd: gpd inputs missing");
+  VTS_REQUIRE(family != VTS_MIXTURE || (choice && pi), "reparam_kl_fwd: mixture needs choice and pi");
+  return vts_ew_reparam_kl_fwd(family, mean, logvar, scale, shape, eps, u, choice, pi, threshold, z, klpart, B,
+                               (int)L, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_reparam_kl_bwd(int family, const float* dz, const float* dklpart, const float* mean, const float* logvar,
+                       const float* scale, const float* shape, const float* eps, const float* u, const float* choice,
+                       const float* pi, float threshold, float* dmean, float* dlogvar, float* dscale, float* dshape,
+                       int64_t B, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && B > 0 && L > 0, "reparam_kl_bwd: bad arguments");
+  VTS_REQUIRE(family == VTS_GPD || (mean && logvar && eps && dmean && dlogvar),
+              "reparam_kl_bwd: gaussian buffers missing");
+  VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape && u && dscale && dshape),
+              "reparam_kl_bwd: gpd buffers missing");
+  VTS_REQUIRE(family != VTS_MIXTURE || (choice && pi), "reparam_kl_bwd: mixture needs choice and pi");
+  return vts_ew_reparam_kl_bwd(family, dz, dklpart, mean, logvar, scale, shape, eps, u, choice, pi, threshold, dmean,
+                               dlogvar, dscale, dshape, B, (int)L, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_elbo_recon_fwd(int family, const float* recon, const float* y, const float* klpart, int64_t nklpart,
+                       const float* pi, float threshold, float beta, float* state, void* workspace,
+                       size_t workspace_bytes, int64_t B, int64_t fs, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && recon && y && klpart && nklpart > 0 && state && workspace && B > 0 &&
+                  fs > 0 && L > 0,
+              "elbo_recon_fwd: bad arguments");
+  VTS_REQUIRE(nklpart == vts_reparam_kl_blocks(B, L), "elbo_recon_fwd: nklpart is not vts_reparam_kl_blocks(B, L)");
+  VTS_REQUIRE(family != VTS_MIXTURE || pi, "elbo_recon_fwd: mixture needs pi");
+  VTS_REQUIRE(workspace_bytes >= vts_elbo_workspace_bytes(B, fs, L), "elbo_recon_fwd: workspace too small");
+  return vts_ew_elbo_recon_fwd(family, recon, y, klpart, (int)nklpart, pi, threshold, beta, B, (int)fs, (int)L,
+                               reinterpret_cast<float*>(workspace), state, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const float* state, const float* grad_out,
+                       float threshold, float* drecon, float* dklpart, int64_t nklpart, float* dpi, int64_t B,
+                       int64_t fs, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 2 && recon && y && state && drecon && dklpart && nklpart > 0 && B > 0 &&
+                  fs > 0,
+              "elbo_recon_bwd: bad arguments");
+  return vts_ew_elbo_recon_bwd(family, recon, y, state, grad_out, threshold, B, (int)fs, drecon, dklpart,
+                               (int)nklpart, dpi, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------ Adam

@@ -52,6 +52,12 @@ SIGNATURES = {
     "vts_elbo_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vts_elbo_fwd": (_int, [_int] + [_ptr] * 7 + [_f32, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64, _ptr]),
     "vts_elbo_bwd": (_int, [_int] + [_ptr] * 8 + [_f32] + [_ptr] * 6 + [_i64, _i64, _i64, _ptr]),
+    "vts_reparam_kl_blocks": (_i64, [_i64, _i64]),
+    "vts_reparam_kl_fwd": (_int, [_int] + [_ptr] * 8 + [_f32, _ptr, _ptr, _i64, _i64, _ptr]),
+    "vts_reparam_kl_bwd": (_int, [_int] + [_ptr] * 10 + [_f32] + [_ptr] * 4 + [_i64, _i64, _ptr]),
+    "vts_elbo_recon_fwd": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64,
+                                  _ptr]),
+    "vts_elbo_recon_bwd": (_int, [_int, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr]),
     "vts_adam_step": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr]),
     "vts_scale": (_int, [_ptr, _ptr, _ptr, _i64, _ptr]),
 }

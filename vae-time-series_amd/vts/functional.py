@@ -270,31 +270,103 @@ class _Reparam(torch.autograd.Function):
         return None, dmean, dlogvar, dscale, dshape, None, None, None, None
 
 
-def reparameterize_gaussian(mean, logvar, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """mean + eps * exp(0.5 * logvar); eps ~ N(0,1) drawn on the device when not fed in."""
+class _ReparamKL(torch.autograd.Function):
+    """_Reparam fused with the KL sums of the loss: returns (z, klpart).  klpart[nblk, 2] holds
+    per-block partial sums of the Gaussian and GPD KL integrands; the loss built from it sends
+    d loss / d klpart back, and backward adds the KL gradient to the sampling gradient in the one
+    pass that writes dmean / dlogvar / dscale / dshape."""
+
+    @staticmethod
+    def forward(ctx, family: int, threshold: float, mean, logvar, scale, shape, eps, u, choice, pi):
+        lib = L.load()
+        ref = mean if mean is not None else scale
+        _need_gpu(ref)
+        B, Ld = ref.shape
+        mean, logvar, scale, shape, eps, u, choice = [_c(t) for t in (mean, logvar, scale, shape, eps, u, choice)]
+        pi_d = None if pi is None else pi.detach().contiguous()
+        z = torch.empty(B, Ld, device=ref.device, dtype=torch.float32)
+        klpart = torch.empty(lib.vts_reparam_kl_blocks(B, Ld), 2, device=ref.device, dtype=torch.float32)
+        L.check(L.timer.call("reparam_kl_fwd", lib.vts_reparam_kl_fwd, family, L.ptr(mean), L.ptr(logvar),
+                             L.ptr(scale), L.ptr(shape), L.ptr(eps), L.ptr(u), L.ptr(choice), L.ptr(pi_d),
+                             threshold, L.ptr(z), L.ptr(klpart), B, Ld, L.stream()), "vts_reparam_kl_fwd")
+        ctx.family, ctx.threshold, ctx.dims = family, threshold, (B, Ld)
+        ctx.save_for_backward(mean, logvar, scale, shape, eps, u, choice, pi_d)
+        return z, klpart
+
+    @staticmethod
+    def backward(ctx, dz, dklpart):
+        lib = L.load()
+        mean, logvar, scale, shape, eps, u, choice, pi_d = ctx.saved_tensors
+        B, Ld = ctx.dims
+        fam = ctx.family
+        dev = (mean if mean is not None else scale).device
+        dz, dklpart = _c(dz), _c(dklpart)
+        new = lambda: torch.empty(B, Ld, device=dev, dtype=torch.float32)
+        dmean = dlogvar = dscale = dshape = None
+        if fam != L.GPD:
+            dmean, dlogvar = new(), new()
+        if fam != L.GAUSSIAN:
+            dscale, dshape = new(), new()
+        L.check(L.timer.call("reparam_kl_bwd", lib.vts_reparam_kl_bwd, fam, L.ptr(dz), L.ptr(dklpart), L.ptr(mean),
+                             L.ptr(logvar), L.ptr(scale), L.ptr(shape), L.ptr(eps), L.ptr(u), L.ptr(choice),
+                             L.ptr(pi_d), ctx.threshold, L.ptr(dmean), L.ptr(dlogvar), L.ptr(dscale), L.ptr(dshape),
+                             B, Ld, L.stream()), "vts_reparam_kl_bwd")
+        return None, None, dmean, dlogvar, dscale, dshape, None, None, None, None
+
+
+class KLSums:
+    """KL partial sums produced while sampling, with the identity of the tensors they were
+    computed from: the ``*_elbo`` functions use them only for exactly those tensors and that
+    threshold, and otherwise read the latent parameters again."""
+
+    def __init__(self, klpart: torch.Tensor, latents, threshold: float):
+        self.klpart, self.latents, self.threshold = klpart, tuple(latents), float(threshold)
+
+    def matches(self, latents, threshold: float) -> bool:
+        return (len(latents) == len(self.latents) and all(a is b for a, b in zip(latents, self.latents))
+                and float(threshold) == self.threshold)
+
+
+def reparameterize_gaussian(mean, logvar, eps: Optional[torch.Tensor] = None, with_kl: bool = False):
+    """mean + eps * exp(0.5 * logvar); eps ~ N(0,1) drawn on the device when not fed in.
+    ``with_kl``: also return the KLSums gaussian_elbo can take in place of a second read."""
     if eps is None:
         eps = torch.randn_like(mean)
+    if with_kl:
+        z, klpart = _ReparamKL.apply(L.GAUSSIAN, 0.0, mean, logvar, None, None, eps, None, None, None)
+        return z, KLSums(klpart, (mean, logvar), 0.0)
     return _Reparam.apply(L.GAUSSIAN, mean, logvar, None, None, eps, None, None, None)
 
 
-def reparameterize_gpd(scale, shape, size=None, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+def reparameterize_gpd(scale, shape, size=None, u: Optional[torch.Tensor] = None,
+                       kl_threshold: Optional[float] = None):
     """scale / shape * ((1 - u) ** (-shape) - 1); u ~ U[0,1) drawn on the device when not fed in
-    (the reference draws it on the CPU, gpd-lstm-DE.py:11, which is why it cannot leave the CPU)."""
+    (the reference draws it on the CPU, gpd-lstm-DE.py:11, which is why it cannot leave the CPU).
+    ``kl_threshold``: also return the KLSums gpd_elbo can take for that threshold."""
     if u is None:
         u = torch.rand(scale.shape if size is None else size, device=scale.device)
+    if kl_threshold is not None:
+        z, klpart = _ReparamKL.apply(L.GPD, float(kl_threshold), None, None, scale, shape, None, u, None, None)
+        return z, KLSums(klpart, (scale, shape), kl_threshold)
     return _Reparam.apply(L.GPD, None, None, scale, shape, None, u, None, None)
 
 
-def reparameterize_mixture(mean, logvar, scale, shape, pi_params, choice=None, eps=None, u=None) -> torch.Tensor:
+def reparameterize_mixture(mean, logvar, scale, shape, pi_params, choice=None, eps=None, u=None,
+                           kl_threshold: Optional[float] = None):
     """Row i is the Gaussian sample iff choice[i] < softmax(pi_params)[0], else the GPD sample
     (mixture-vae-DE.py:94-107 without the per-row Python loop).  Draw order when noise is not fed
-    in follows the reference: choice, eps, u."""
+    in follows the reference: choice, eps, u.
+    ``kl_threshold``: also return the KLSums mixture_elbo can take for that threshold."""
     if choice is None:
         choice = torch.rand(mean.shape[0], device=mean.device)
     if eps is None:
         eps = torch.randn_like(mean)
     if u is None:
         u = torch.rand(mean.shape, device=mean.device)
+    if kl_threshold is not None:
+        z, klpart = _ReparamKL.apply(L.MIXTURE, float(kl_threshold), mean, logvar, scale, shape, eps, u, choice,
+                                     pi_params)
+        return z, KLSums(klpart, (mean, logvar, scale, shape), kl_threshold)
     return _Reparam.apply(L.MIXTURE, mean, logvar, scale, shape, eps, u, choice, pi_params)
 
 
@@ -344,18 +416,63 @@ class _Elbo(torch.autograd.Function):
         return None, drecon, None, dmean, dlogvar, dscale, dshape, dpi, None, None
 
 
-def gaussian_elbo(pred, y, mean, logvar, beta: float = 0.001) -> torch.Tensor:
-    """mse(pred, y) + beta * mean_B(-0.5 * sum_L(1 + logvar - mean^2 - exp(logvar)))."""
+class _ElboRecon(torch.autograd.Function):
+    """_Elbo with the KL sums taken from _ReparamKL's klpart instead of a second read of the
+    latent parameters; backward returns drecon, d loss / d klpart and dpi."""
+
+    @staticmethod
+    def forward(ctx, family: int, recon, y, klpart, pi, threshold: float, beta: float, Ld: int):
+        _need_gpu(recon)
+        lib = L.load()
+        recon, y, klpart, pi = recon.contiguous(), y.contiguous(), klpart.contiguous(), _c(pi)
+        B = recon.shape[0]
+        fs = recon.numel() // B
+        state = torch.empty(16, device=recon.device, dtype=torch.float32)
+        ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
+        ws = L.workspace(ws_bytes, recon.device)
+        L.check(L.timer.call("elbo_recon_fwd", lib.vts_elbo_recon_fwd, family, L.ptr(recon), L.ptr(y),
+                             L.ptr(klpart), klpart.shape[0], L.ptr(pi), threshold, beta, L.ptr(state), L.wptr(ws),
+                             ws_bytes, B, fs, Ld, L.stream()), "vts_elbo_recon_fwd")
+        ctx.family, ctx.threshold, ctx.dims = family, threshold, (B, fs, klpart.shape[0])
+        ctx.save_for_backward(recon, y, state)
+        return state[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        recon, y, state = ctx.saved_tensors
+        B, fs, nkl = ctx.dims
+        dev = recon.device
+        gout = gout.contiguous().reshape(1)
+        drecon = torch.empty_like(recon)
+        dklpart = torch.empty(nkl, 2, device=dev, dtype=torch.float32)
+        dpi = torch.empty(2, device=dev, dtype=torch.float32) if ctx.family == L.MIXTURE else None
+        L.check(L.timer.call("elbo_recon_bwd", lib.vts_elbo_recon_bwd, ctx.family, L.ptr(recon), L.ptr(y),
+                             L.ptr(state), L.ptr(gout), ctx.threshold, L.ptr(drecon), L.ptr(dklpart), nkl,
+                             L.ptr(dpi), B, fs, L.stream()), "vts_elbo_recon_bwd")
+        return None, drecon, None, dklpart, dpi, None, None, None
+
+
+def gaussian_elbo(pred, y, mean, logvar, beta: float = 0.001, kl: Optional[KLSums] = None) -> torch.Tensor:
+    """mse(pred, y) + beta * mean_B(-0.5 * sum_L(1 + logvar - mean^2 - exp(logvar))).
+    ``kl``: sums from reparameterize_gaussian(with_kl=True), used when they belong to (mean, logvar)."""
+    if kl is not None and kl.matches((mean, logvar), 0.0):
+        return _ElboRecon.apply(L.GAUSSIAN, pred, y, kl.klpart, None, 0.0, beta, mean.shape[1])
     return _Elbo.apply(L.GAUSSIAN, pred, y, mean, logvar, None, None, None, 0.0, beta)
 
 
-def gpd_elbo(recon, y, scale, shape, threshold: float = 95.0, beta: float = 0.001) -> torch.Tensor:
+def gpd_elbo(recon, y, scale, shape, threshold: float = 95.0, beta: float = 0.001,
+             kl: Optional[KLSums] = None) -> torch.Tensor:
     """mse(recon, y) + beta * mean(log(scale) + log(1 + shape * threshold / scale))."""
+    if kl is not None and kl.matches((scale, shape), threshold):
+        return _ElboRecon.apply(L.GPD, recon, y, kl.klpart, None, float(threshold), beta, scale.shape[1])
     return _Elbo.apply(L.GPD, recon, y, None, None, scale, shape, None, float(threshold), beta)
 
 
 def mixture_elbo(recon, y, mean, logvar, scale, shape, pi_params, threshold: float = 95.0,
-                 beta: float = 0.001) -> torch.Tensor:
+                 beta: float = 0.001, kl: Optional[KLSums] = None) -> torch.Tensor:
     """mse + pi_g * (mse over |y| <= threshold + beta * KL_gaussian) + pi_p * (mse + beta * KL_gpd),
     (pi_g, pi_p) = softmax(pi_params).  NaN when no |y| <= threshold, as in the reference."""
+    if kl is not None and kl.matches((mean, logvar, scale, shape), threshold):
+        return _ElboRecon.apply(L.MIXTURE, recon, y, kl.klpart, pi_params, float(threshold), beta, mean.shape[1])
     return _Elbo.apply(L.MIXTURE, recon, y, mean, logvar, scale, shape, pi_params, float(threshold), beta)

@@ -120,17 +120,21 @@ class GaussianVAE(nn.Module):
         self.encoder = GaussianEncoder(input_dim, lstm_output_dim, latent_dim)
         self.decoder = GaussianDecoder(latent_dim, future_steps)
         self.beta = beta
+        self._kl = None
 
     def reparameterize(self, mean, logvar, eps=None):
         return F.reparameterize_gaussian(mean, logvar, eps)
 
     def forward(self, x, noise: Noise = None):
         z_mean, z_log_var = self.encoder(x)
-        z = self.reparameterize(z_mean, z_log_var, None if noise is None else noise.get("eps"))
+        # sampling also leaves the KL sums of these exact tensors for loss_function
+        z, self._kl = F.reparameterize_gaussian(z_mean, z_log_var, None if noise is None else noise.get("eps"),
+                                                with_kl=True)
         return self.decoder(z), z_mean, z_log_var
 
     def loss_function(self, forecasting, y, z_mean, z_log_var):
-        return F.gaussian_elbo(forecasting, y, z_mean, z_log_var, self.beta)
+        kl, self._kl = self._kl, None
+        return F.gaussian_elbo(forecasting, y, z_mean, z_log_var, self.beta, kl=kl)
 
 
 # --------------------------------------------------------------------- GPD and mixture VAEs
@@ -186,6 +190,7 @@ class GPDVAE(nn.Module):
         self.encoder = DeepEncoder(input_dim, lstm_output_dim, latent_dim, gaussian_heads=False)
         self.decoder = DeepDecoder(latent_dim, future_steps)
         self.beta, self.threshold = beta, threshold
+        self._kl = None
 
     def reparameterize(self, scale, shape, u=None):
         return F.reparameterize_gpd(scale, shape, scale.size(), u)
@@ -193,12 +198,14 @@ class GPDVAE(nn.Module):
     def forward(self, x, noise: Noise = None):
         # draw order of the reference: encoder dropout, u, decoder dropout
         scale, shape = self.encoder(x, noise)
-        z = self.reparameterize(scale, shape, None if noise is None else noise.get("u"))
+        z, self._kl = F.reparameterize_gpd(scale, shape, scale.size(), None if noise is None else noise.get("u"),
+                                           kl_threshold=self.threshold)
         return self.decoder(z, noise), scale, shape
 
     def loss_function(self, reconstructed, y, scale, shape, threshold=None):
         thr = self.threshold if threshold is None else threshold
-        return F.gpd_elbo(reconstructed, y, scale, shape, thr, self.beta)
+        kl, self._kl = self._kl, None
+        return F.gpd_elbo(reconstructed, y, scale, shape, thr, self.beta, kl=kl)
 
 
 class MixtureVAE(nn.Module):
@@ -210,6 +217,7 @@ class MixtureVAE(nn.Module):
         self.encoder = DeepEncoder(input_dim, lstm_output_dim, latent_dim, gaussian_heads=True)
         self.decoder = DeepDecoder(latent_dim, future_steps)
         self.beta, self.threshold = beta, threshold
+        self._kl = None
         self.pi_params = nn.Parameter(torch.tensor([3.0, 0.01]))
 
     def reparameterize(self, mean, logvar, scale, shape, choice=None, eps=None, u=None):
@@ -219,12 +227,14 @@ class MixtureVAE(nn.Module):
         # draw order of the reference: encoder dropout, choice, eps, u, decoder dropout
         mean, logvar, scale, shape = self.encoder(x, noise)
         n = noise or {}
-        z = self.reparameterize(mean, logvar, scale, shape, n.get("choice"), n.get("eps"), n.get("u"))
+        z, self._kl = F.reparameterize_mixture(mean, logvar, scale, shape, self.pi_params, n.get("choice"),
+                                               n.get("eps"), n.get("u"), kl_threshold=self.threshold)
         return self.decoder(z, noise), mean, logvar, scale, shape
 
     def loss_function(self, reconstructed, y, mean, logvar, scale, shape, threshold=None):
         thr = self.threshold if threshold is None else threshold
-        return F.mixture_elbo(reconstructed, y, mean, logvar, scale, shape, self.pi_params, thr, self.beta)
+        kl, self._kl = self._kl, None
+        return F.mixture_elbo(reconstructed, y, mean, logvar, scale, shape, self.pi_params, thr, self.beta, kl=kl)
 
 
 def build_model(kind: str, input_dim: int, lstm_output_dim: int, latent_dim: int, future_steps: int = 1,
