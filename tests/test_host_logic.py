@@ -126,3 +126,18 @@ def test_noise_draw_order_matches_reference(golden):
         assert set(n) == set(g["noise"])
         for k in n:
             assert n[k].shape == g["noise"][k].shape
+
+
+def test_recurrent_ring_registers_are_never_touched_in_flight():
+    """The bf16x3 recurrent kernels fill their W_hh register ring with inline-asm loads and wait
+    for them with hand-counted s_waitcnt; tools/check_ring_registers.py re-derives from the
+    generated gfx950 ISA that no instruction touches a ring register while its load can still be
+    outstanding (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ring_registers.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

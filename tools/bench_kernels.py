@@ -64,10 +64,10 @@ def main():
                                                                    L.wptr(gates), B, T, Cin, H, MODE, st)),
         ("recurrent_fwd", rec_f, lambda: lib.vts_lstm_recurrent_fwd(L.wptr(gates), L.wptr(cells), L.ptr(hseq),
                                                                       L.ptr(h_last), None, L.ptr(w_hh), L.wptr(rws),
-                                                                      rws_b, B, T, H, 0, st)),
+                                                                      rws_b, B, T, H, MODE, st)),
         ("recurrent_bwd", rec_f, lambda: lib.vts_lstm_recurrent_bwd(L.wptr(gates), L.wptr(cells), None,
                                                                       L.ptr(dh_last), None, L.ptr(w_hh), L.ptr(db),
-                                                                      L.ptr(db), 0, L.wptr(rws), rws_b, B, T, H, 0, st)),
+                                                                      L.ptr(db), 0, L.wptr(rws), rws_b, B, T, H, MODE, st)),
         ("dgrad(H)", rec_f, lambda: lib.vts_lstm_dgrad(L.wptr(gates), L.ptr(w_ih2), L.wptr(dx), B, T, H, H, MODE, st)),
         ("wgrad_ih", inproj_f, lambda: lib.vts_lstm_wgrad(L.wptr(gates), L.ptr(x), 0, L.ptr(dw_ih), 0, L.wptr(wg),
                                                           wg_b, B, T, Cin, H, MODE, st)),

@@ -401,8 +401,6 @@ __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmP
 // split residuals are ~2^-16 relative).  Tile 128 x 128 x 32, LDS rows hold 32 k values (k
 // contiguous, 80-byte row pitch) in two planes (hi, lo) per operand; the C/D layout of the 16x16
 // bf16 MFMA equals the f32 one, so mapping and epilogue are shared with the f32 kernel.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK3 = 32;                 // k elements per main-loop iteration
 constexpr int ROWB = 80;                // LDS row pitch in bytes (32 bf16 + 16 B pad)
 constexpr int PLANE = 128 * ROWB;       // one plane (hi or lo) of one operand tile
@@ -414,24 +412,6 @@ constexpr int PLANE = 128 * ROWB;       // one plane (hi or lo) of one operand t
 #endif
 constexpr int NSUB3 = VTS_GEMM3_NSUB;   // 32-deep k sub-chunks staged per barrier pair
 constexpr size_t GEMM3_LDS_BYTES = 4ul * PLANE * NSUB3;   // per sub-chunk: A hi, A lo, B hi, B lo
-
-// x -> (hi, lo) for two values at a time: one packed round-to-nearest conversion gives both hi
-// halves, two integer ops widen them back to fp32, one packed conversion rounds the residuals
-// (6 VALU instructions per pair; v_cvt_pk_bf16_f32 has no builtin, a plain cast costs ~9).
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-  hi = cvt_pk_bf16(x0, x1);
-  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
-  lo = cvt_pk_bf16(x0 - h0, x1 - h1);
-}
-__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
-  split2(x0, x1, hi.x, lo.x);
-  split2(x2, x3, hi.y, lo.y);
-}
 
 __device__ __forceinline__ void load4(const float* __restrict__ p, int nvalid, float (&v)[4]) {
   if (nvalid >= 4) {

@@ -1,0 +1,347 @@
+// Persistent LSTM recurrence kernels, bf16x3 on v_mfma_f32_16x16x32_bf16.
+//
+// Same ownership as the fp32 kernels (lstm_rec_f32.hip): one workgroup = 16 windows for the whole
+// sequence, wave w = hidden units [w*JPW*16, (w+1)*JPW*16) for all four gates, tile16 buffers in
+// MFMA accumulator order.  The recurrent product is evaluated as
+//     h_hi.W_hi + h_lo.W_hi + h_hi.W_lo        (x = x_hi + x_lo, both bf16; fp32 accumulate)
+// which costs 3/16 of the fp32 matrix-core time and keeps fp32-level accuracy (the dropped
+// lo.lo term is ~2^-16 relative).  W_hh is split once per call by the pack kernels into a
+// fragment-ordered bf16 image of the same size as the fp32 one (hi + lo = 4 bytes per weight); h
+// (forward) and dA (backward) are split when they are written to LDS, where they live as two bf16
+// planes.  With the matrix-core time out of the way the kernels run at the rate the XCD's L2
+// delivers the W_hh image to 32 CUs at once (~70 GB/s per CU), so part of the image stays in LDS.
+#include "lstm_rec_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// value of the neighbouring lane (lane ^ 1) without touching LDS: DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <int H>
+struct Rec3Cfg {
+  using C = RecCfg<H>;
+  static constexpr int NT = C::JPW * 4;             // forward: accumulator tiles per wave
+  static constexpr int KS_F = H / 32;               // forward k-steps (32 k each)
+  static constexpr int NU_F = 2 * KS_F;             // forward ring units per step: (k-step, hi | lo)
+  static constexpr int KS_B = (4 * H) / 32;         // backward k-steps
+  static constexpr int NU_B = KS_B / 2;             // backward ring units per step: 2 k-steps x (hi, lo)
+  static constexpr int UNIT = NT * 64;              // 16-byte fragments per unit and wave (both directions)
+  static constexpr int CH_F = H / 8;                // 16-byte chunks per row of an h plane
+  static constexpr int CH_B = (4 * H) / 8;          // ... of a dA plane
+  static constexpr int SWZ_F = (CH_F < 16 ? CH_F : 16) - 1;
+  // h planes + one half-unit (NT/2 fragments per lane) for every second k-step
+  static constexpr size_t LDS_F = 2ul * 2 * 16 * H * 2 + (size_t)(KS_F / 2) * (NT / 2) * C::NW * 64 * 16;
+  static constexpr size_t LDS_B = 2ul * 2 * 16 * 4 * H * 2;
+};
+
+// ---- weight packing ---------------------------------------------------------------------------
+// One thread per 16-byte fragment element (8 consecutive k of one column, hi or lo plane).
+// forward image : [wave][u = 2*ks + p][i = jl*4 + gate][lane]  ->
+//                 W_hh[gate*H + (wave*JPW+jl)*16 + (lane&15)][32*ks + 8*(lane>>4) + e],  e = 0..7
+// backward image: [wave][u][i = (kl*2 + p)*JPW + jl][lane], ks = 2*u + kl  ->
+//                 W_hh[(e&3)*H + 8*ks + 2*(lane>>4) + (e>>2)][(wave*JPW+jl)*16 + (lane&15)]
+//                 (k slot 4*j + gate, the order the backward kernel writes dA in)
+template <int H, bool BWD>
+__global__ void pack_whh3_kernel(const float* __restrict__ W, u32x4* __restrict__ out) {
+  using C = RecCfg<H>;
+  using R = Rec3Cfg<H>;
+  const int total = H * H;   // 4H*H weights * 2 planes / 8 per fragment
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int i = rest % R::NT; rest /= R::NT;
+    const int NU = BWD ? R::NU_B : R::NU_F;
+    const int u = rest % NU;
+    const int wave = rest / NU;
+    float v[8];
+    int p;
+    if (!BWD) {
+      const int ks = u >> 1;
+      p = u & 1;
+      const int jl = i >> 2, gate = i & 3;
+      const int row = gate * H + (wave * C::JPW + jl) * 16 + (lane & 15);
+      const int k0 = 32 * ks + 8 * (lane >> 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = W[row * H + k0 + e];
+    } else {
+      const int jl = i % C::JPW;
+      const int kp = i / C::JPW;
+      p = kp & 1;
+      const int ks = 2 * u + (kp >> 1);
+      const int col = (wave * C::JPW + jl) * 16 + (lane & 15);
+      const int j0 = 8 * ks + 2 * (lane >> 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = W[((e & 3) * H + j0 + (e >> 2)) * H + col];
+    }
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hi, lo;
+      split2(v[2 * q], v[2 * q + 1], hi, lo);
+      o[q] = p ? lo : hi;
+    }
+    out[idx] = o;
+  }
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+// W_hh stream.  The image is consumed in half-units of UT = NT/2 fragments (8 KiB per wave at
+// H = 256): per k-step  hi[0..UT), hi[UT..NT), lo[0..UT), lo[UT..NT).  A ring of four register
+// buffers keeps three half-units in flight.  The loads are issued as inline asm and waited for with
+// hand-counted s_waitcnt: left to the compiler, the wait at the loop back-edge is vmcnt(0), which
+// drains the ring once per iteration and exposes a full L2 round trip each time.  Loads return in
+// order, so "at most N younger VMEM operations outstanding" proves a buffer has landed; operations
+// the compiler issues in between (gate loads, the previous step's stores) only make a given N
+// stricter.  The waits carry the buffer as an in/out operand so that no use can move above them,
+// and so do the loads: every definition of a ring buffer is tied to the previous one, which keeps
+// each buffer in the same physical registers around the loops.  (A fresh output register per
+// load lets the allocator pick different registers per iteration and reconcile them with moves
+// at the back-edge - moves that would copy registers whose data is still in flight.)
+// tools/check_ring_registers.py verifies on the generated ISA that nothing but these loads, the
+// LDS reads of the resident part and the MFMAs ever touches the ring registers.
+template <int UT>
+__device__ __forceinline__ void w_issue(u32x4 (&w)[UT], const void* sbase, unsigned voff) {
+  static_assert(UT == 2 || UT == 4 || UT == 8, "half-unit of 2, 4 or 8 fragments");
+#pragma unroll
+  for (int i = 0; i < UT; ++i) {
+    if (i < 4)
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(w[i]) : "v"(voff), "s"(sbase), "n"((i & 3) * 1024));
+    else
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
+                   : "+v"(w[i]) : "v"(voff + 4096u), "s"(sbase), "n"((i & 3) * 1024));
+  }
+}
+template <int N, int UT>
+__device__ __forceinline__ void w_wait(u32x4 (&w)[UT]) {
+  if constexpr (UT == 8)
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]),
+                 "+v"(w[6]), "+v"(w[7]) : "n"(N));
+  else if constexpr (UT == 4)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+  else
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
+}
+
+// Arguments as lstm_rec_fwd_kernel.  LDS: h as bf16 planes [buffer 2][hi, lo][16][H], the 16-byte
+// chunk index XOR-ed with the row (conflict-free fragment reads without padding), then the
+// second lo half-unit of every odd k-step (a quarter of the lo plane, 1/8 of the image).
+template <int H>
+__global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
+    float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
+    float* __restrict__ clast, const u32x4* __restrict__ Wp, int B, int T) {
+  using C = RecCfg<H>;
+  using R = Rec3Cfg<H>;
+  constexpr int NT = R::NT;
+  constexpr int UT = NT / 2;
+  constexpr int KS = R::KS_F;
+  static_assert(KS % 2 == 0, "k-steps are processed in pairs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  constexpr int PLANE = 16 * H * 2;                            // bytes of one bf16 plane
+  u32x4* wlds = reinterpret_cast<u32x4*>(smem3 + 4 * PLANE);   // [KS/2][UT][NW*64]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int bt = blockIdx.x;
+  const int b0 = bt * 16;
+
+  f32x4 c[C::JPW];
+#pragma unroll
+  for (int jl = 0; jl < C::JPW; ++jl) c[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's part of the image: [ks][hi | lo][NT][64 lanes] fragments of 16 bytes
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(Wp) + (size_t)wave * (2 * KS * NT * 1024);
+  const unsigned voff = lane * 16;
+  // half-unit q of k-step ks: q = 0, 1 hi halves, 2, 3 lo halves
+  auto hu_ptr = [&](int ks, int q) { return wbase + (size_t)((ks * 4 + q) * UT) * 1024; };
+  // every lane re-reads from LDS only what it wrote itself, so no barrier is needed
+#pragma unroll 1
+  for (int n = 0; n < KS / 2; ++n) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(hu_ptr(2 * n + 1, 3)) + lane;
+#pragma unroll
+    for (int i = 0; i < UT; ++i) wlds[(n * UT + i) * (C::NW * 64) + tid] = src[i * 64];
+  }
+  auto load_w_lds = [&](u32x4 (&w)[UT], int slot) {
+#pragma unroll
+    for (int i = 0; i < UT; ++i) w[i] = wlds[(slot * UT + i) * (C::NW * 64) + tid];
+  };
+  auto load_g = [&](f32x4 (&gv)[NT], int t) {
+    const float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+#pragma unroll
+    for (int jl = 0; jl < C::JPW; ++jl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        gv[jl * 4 + q] = ld_stream(Gt + (long)(q * C::JT + wave * C::JPW + jl) * 256);
+  };
+
+  float* hseq_wg = hseq + (long)b0 * T * H;   // uniform base; lane offsets stay below 16*T*H
+  f32x4 gnext[NT];
+  load_g(gnext, 0);
+  u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
+#pragma unroll
+  for (int i = 0; i < UT; ++i) w0[i] = w1[i] = w2[i] = w3[i] = u32x4{0u, 0u, 0u, 0u};
+  w_issue<UT>(w0, hu_ptr(0, 0), voff);
+  w_issue<UT>(w1, hu_ptr(0, 1), voff);
+  w_issue<UT>(w2, hu_ptr(0, 2), voff);
+
+  // byte offset of this lane's A fragment (row r, chunk 4*ks + g) inside a plane
+  auto a_off = [&](int ks) { return r * (H * 2) + (((4 * ks + g) ^ (r & R::SWZ_F)) << 4); };
+
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    const unsigned char* hcur = smem3 + cur * (2 * PLANE);
+    unsigned char* hnxt = smem3 + nxt * (2 * PLANE);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = gnext[i];
+    if (t + 1 < T) load_g(gnext, t + 1);
+
+    if (t > 0) {
+      auto lds_a = [&](int plane, int ks) {
+        return *reinterpret_cast<const u32x4*>(hcur + plane * PLANE + a_off(ks));
+      };
+      u32x4 ah = lds_a(0, 0), al = lds_a(1, 0);
+      // MFMAs of one half-unit: tiles [half*UT, half*UT + UT); sched_barrier(0) pins the issue order
+      auto mma_hi = [&](const u32x4 (&w)[UT], int half) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < UT; ++i)
+          acc[half * UT + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), as_bf16x8(w[i]),
+                                                                      acc[half * UT + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < UT; ++i)
+          acc[half * UT + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(w[i]),
+                                                                      acc[half * UT + i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mma_lo = [&](const u32x4 (&w)[UT], int half) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < UT; ++i)
+          acc[half * UT + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(w[i]),
+                                                                      acc[half * UT + i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // One k-step.  RES: its last half-unit comes from LDS instead of the stream.  Younger loads
+      // at each wait: the two (RES) or three half-units issued after the one being waited for.
+      auto kstep = [&](int ks, auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+        constexpr int NY = (RES ? 2 : 3) * UT;
+        if constexpr (RES) load_w_lds(w3, ks >> 1);
+        else w_issue<UT>(w3, hu_ptr(ks, 3), voff);
+        const int kn = (ks + 1) & (KS - 1);
+        const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);   // A fragments of the next k-step
+        w_wait<NY, UT>(w0);
+        mma_hi(w0, 0);
+        w_issue<UT>(w0, hu_ptr(kn, 0), voff);
+        w_wait<NY, UT>(w1);
+        mma_hi(w1, 1);
+        w_issue<UT>(w1, hu_ptr(kn, 1), voff);
+        w_wait<NY, UT>(w2);
+        mma_lo(w2, 0);
+        w_issue<UT>(w2, hu_ptr(kn, 2), voff);
+        if constexpr (!RES) w_wait<3 * UT, UT>(w3);
+        mma_lo(w3, 1);
+        ah = nh;
+        al = nl;
+      };
+#pragma unroll 1
+      for (int ks = 0; ks < KS; ks += 2) {
+        kstep(ks, std::false_type{});
+        kstep(ks + 1, std::true_type{});
+      }
+    }
+
+    // cell update, lane-local: acc[jl*4+q][reg] is gate q of window row 4g+reg, hidden jt*16+r
+    float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+#pragma unroll
+    for (int jl = 0; jl < C::JPW; ++jl) {
+      const int jt = wave * C::JPW + jl;
+      f32x4 gi, gf, gg, go;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        gi[reg] = fast_sigmoid(acc[jl * 4 + 0][reg]);
+        gf[reg] = fast_sigmoid(acc[jl * 4 + 1][reg]);
+        gg[reg] = fast_tanh(acc[jl * 4 + 2][reg]);
+        go[reg] = fast_sigmoid(acc[jl * 4 + 3][reg]);
+        c[jl][reg] = gf[reg] * c[jl][reg] + gi[reg] * gg[reg];
+        const float hv = go[reg] * fast_tanh(c[jl][reg]);
+        // h -> LDS as bf16 hi / lo pairs: the even lane of each pair writes the two hi halves,
+        // the odd lane the two lo halves (one 4-byte store per lane)
+        const float other = lane_xor1(hv);
+        const bool odd = r & 1;
+        unsigned hi, lo;
+        split2(odd ? other : hv, odd ? hv : other, hi, lo);
+        const int row = 4 * g + reg;
+        const int col = jt * 16 + (r & ~1);
+        const int off = row * (H * 2) + ((((col >> 3) ^ (row & R::SWZ_F)) << 4) | ((col & 7) << 1));
+        *reinterpret_cast<unsigned*>(hnxt + (odd ? PLANE : 0) + off) = odd ? lo : hi;
+        if (b0 + row < B) {
+          hseq_wg[(unsigned)((row * T + t) * H + jt * 16 + r)] = hv;
+          if (t == T - 1) {
+            if (hlast != nullptr) hlast[(long)(b0 + row) * H + jt * 16 + r] = hv;
+            if (clast != nullptr) clast[(long)(b0 + row) * H + jt * 16 + r] = c[jl][reg];
+          }
+        }
+      }
+      st_stream(Gt + (long)(0 * C::JT + jt) * 256, gi);
+      st_stream(Gt + (long)(1 * C::JT + jt) * 256, gf);
+      st_stream(Gt + (long)(2 * C::JT + jt) * 256, gg);
+      st_stream(Gt + (long)(3 * C::JT + jt) * 256, go);
+      st_stream(cseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4, c[jl]);
+    }
+    lds_barrier();
+  }
+  // The ring wrapped into a step that does not exist.  Waiting on the buffers here keeps them live
+  // to the end: were they dead after their last MFMA, the allocator would reuse registers that
+  // these loads still write to.
+  w_wait<0, UT>(w0);
+  w_wait<0, UT>(w1);
+  w_wait<0, UT>(w2);
+}
+
+template <int H>
+int run_fwd3(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B,
+             int T, hipStream_t stream) {
+  using C = RecCfg<H>;
+  using R = Rec3Cfg<H>;
+  u32x4* img = reinterpret_cast<u32x4*>(Wp);
+  hipLaunchKernelGGL((pack_whh3_kernel<H, false>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
+  VTS_CHECK_LAUNCH("pack_whh3_fwd");
+  static bool attr_set = false;
+  if (!attr_set && R::LDS_F > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec3_fwd_kernel<H>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_F);
+    if (e != hipSuccess) {
+      vts_set_error("lstm_rec3_fwd: cannot reserve %zu B of LDS: %s", R::LDS_F, hipGetErrorString(e));
+      return VTS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_rec3_fwd_kernel<H>, dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_F, stream, G, cseq, hseq,
+                     hlast, clast, img, B, T);
+  VTS_CHECK_LAUNCH("lstm_rec3_fwd");
+  return VTS_OK;
+}
+
+}  // namespace
+
+bool vts_lstm_rec3_supported(int H) { return H == 64 || H == 128 || H == 256; }
+
+int vts_lstm_rec3_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
+                      int B, int T, int H, hipStream_t stream) {
+  switch (H) {
+    case 64: return run_fwd3<64>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+    case 128: return run_fwd3<128>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+    case 256: return run_fwd3<256>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+  }
+  vts_set_error("lstm bf16x3 recurrence: hidden size %d not supported (64, 128, 256)", H);
+  return VTS_ERR_UNSUPPORTED;
+}

@@ -21,6 +21,9 @@ int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, lo
 int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, float* dW, float* slabs, int ksplit,
                        int M, int N, int K, int accumulate, hipStream_t stream);
 bool vts_lstm_hidden_supported(int H);
+bool vts_lstm_rec3_supported(int H);
+int vts_lstm_rec3_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
+                      int B, int T, int H, hipStream_t stream);
 int vts_lstm_rec_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B, int T,
                      int H, hipStream_t stream);
 int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
@@ -155,6 +158,10 @@ int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_las
               "lstm_recurrent_fwd: gates, cells, hseq, h_last and workspace must be 16-byte aligned");
   VTS_REQUIRE(workspace_bytes >= vts_lstm_recurrent_workspace_bytes(B, T, H),
               "lstm_recurrent_fwd: workspace %zu B too small", workspace_bytes);
+  // bf16x3 recurrence for the hidden sizes it is built for; smaller ones stay on the fp32 kernel
+  if (dtype_mode == 1 && vts_lstm_rec3_supported((int)H))
+    return vts_lstm_rec3_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), (int)B,
+                             (int)T, (int)H, reinterpret_cast<hipStream_t>(stream));
   return vts_lstm_rec_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), (int)B,
                           (int)T, (int)H, reinterpret_cast<hipStream_t>(stream));
 }

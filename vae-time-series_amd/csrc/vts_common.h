@@ -45,3 +45,26 @@ static inline int vts_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __host__ __device__ static inline long vts_tile16_offset(long m, long n, long N) {
   return ((m >> 4) * (N >> 4) + (n >> 4)) * 256 + ((((m & 15) >> 2) * 16 + (n & 15)) << 2) + (m & 3);
 }
+
+// ---- bf16x3 operand split ----------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x -> (hi, lo) for two values at a time: one packed round-to-nearest conversion gives both hi
+// halves, two integer ops widen them back to fp32, one packed conversion rounds the residuals
+// (6 VALU instructions per pair; v_cvt_pk_bf16_f32 has no builtin, a plain cast costs ~9).
+static __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+static __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+  lo = cvt_pk_bf16(x0 - h0, x1 - h1);
+}
+static __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
+  split2(x0, x1, hi.x, lo.x);
+  split2(x2, x3, hi.y, lo.y);
+}
+
