@@ -5,7 +5,7 @@ The ring buffers are filled by inline-asm global loads whose data arrives asynch
 kernel is only correct if, between a load and the hand-counted s_waitcnt that proves it landed,
 nothing reads or copies those registers.  This script compiles the source to assembly and checks
 for every lstm_rec3_* kernel that no instruction (MFMA, move, spill, another load) touches a
-register written by such a load (`global_load_dwordx4 v[a:b], vN, s[c:d] offset:K`) while the
+register written by such a load (`global_load_dwordx4 v[a:b] or a[a:b], vN, s[c:d] offset:K`) while the
 load can still be outstanding, which also re-derives every hand-counted vmcnt from the
 instruction stream.  Exit status 1 and a listing on any violation.
 
@@ -19,16 +19,16 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 
 
 def regs_of(text):
     out = set()
     for m in REG.finditer(text):
         if m.group(1) is not None:
-            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
         else:
-            out.add(int(m.group(3)))
+            out.add((m.group(4), int(m.group(5))))
     return out
 
 
@@ -47,62 +47,109 @@ def kernels(asm):
 
 
 def check(name, body):
-    """Walk the kernel in program order, every loop body twice (so that state carried over a
-    back-edge is seen), with a FIFO of outstanding ring loads.  Only ring loads are modelled:
-    other VMEM operations can only make a given vmcnt(N) stricter than the model assumes (loads
-    return in order) or, for stores, may retire early, so leaving them out is the conservative
-    reading.  A register is in flight from its ring load until an s_waitcnt vmcnt(N) leaves at most
-    N younger ring loads outstanding; any instruction touching an in-flight register is an error."""
-    code, labels = [], {}
+    """Forward dataflow over the kernel's control-flow graph.  The state is the FIFO of
+    outstanding ring loads (register sets, oldest first).  Only ring loads are modelled: other
+    VMEM operations can only make a given vmcnt(N) stricter than the model assumes (loads return in
+    order) or, for stores, may retire early, so leaving them out is the conservative reading.  A
+    register is in flight from its ring load until an s_waitcnt vmcnt(N) leaves at most N younger
+    ring loads outstanding; any instruction touching an in-flight register is an error."""
+    code, labels, from_asm, in_asm = [], {}, set(), False
     for l in body:
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
         l = l.split(";")[0].strip()
         if not l or l.startswith(".") and not l.endswith(":"):
             continue
         if l.endswith(":"):
             labels[l[:-1]] = len(code)
             continue
+        if in_asm:
+            from_asm.add(len(code))       # instruction text written by the kernel source, not the compiler
         code.append(l)
-    ring_load = re.compile(r"^global_load_dwordx4 (v\[\d+:\d+\]), v\d+, s\[\d+:\d+\]")
-    if not any(ring_load.match(l) for l in code):
+    ring_re = re.compile(r"^global_load_dwordx4 ([va]\[\d+:\d+\]), v\d+, s\[\d+:\d+\]")
+    is_ring = [bool(ring_re.match(l)) and i in from_asm for i, l in enumerate(code)]
+    if not any(is_ring):
         return [f"{name}: no ring loads found"]
-    fifo, inflight, bad, seen = [], set(), [], set()
 
-    def step(l):
-        m = ring_load.match(l)
-        op = l.split()[0]
+    # basic blocks
+    br = re.compile(r"^s_(cbranch_\w+|branch) (\S+)$")
+    leaders = {0} | set(labels.values())
+    for i, l in enumerate(code):
+        if br.match(l) or l.startswith("s_endpgm"):
+            leaders.add(i + 1)
+    starts = sorted(x for x in leaders if x < len(code))
+    block_of = {s: (s, e) for s, e in zip(starts, starts[1:] + [len(code)])}
+
+    def succs(s):
+        e = block_of[s][1]
+        last = code[e - 1]
+        m = br.match(last)
+        out = []
+        if last.startswith("s_endpgm"):
+            return out
         if m:
-            dst = regs_of(m.group(1))
-            if dst & inflight:
-                bad.append(f"{name}: `{l}` reloads registers still in flight")
-            fifo.append(dst)
-            inflight.update(dst)
-            return
-        if op == "s_waitcnt":
-            w = re.search(r"vmcnt\((\d+)\)", l)
-            if w:
-                while len(fifo) > int(w.group(1)):
-                    inflight.difference_update(fifo.pop(0))
-            return
-        if op.startswith("s_"):
-            return
-        hit = regs_of(l[len(op):]) & inflight
-        if hit and l not in seen:
-            seen.add(l)
-            bad.append(f"{name}: `{l}` touches in-flight ring registers {sorted(hit)[:8]}")
+            if m.group(2) in labels:
+                out.append(labels[m.group(2)])
+            if m.group(1) != "branch" and e < len(code):
+                out.append(e)
+        elif e < len(code):
+            out.append(e)
+        return out
 
-    def walk(lo, hi, depth):
-        i = lo
-        while i < hi:
+    bad, seen = [], set()
+
+    def run_block(s, fifo, report):
+        fifo = [set(x) for x in fifo]
+        for i in range(*block_of[s]):
             l = code[i]
-            step(l)
-            m = re.match(r"^s_cbranch_\w+ (\S+)$", l) or re.match(r"^s_branch (\S+)$", l)
-            if m and m.group(1) in labels and lo <= labels[m.group(1)] <= i and depth < 4:
-                walk(labels[m.group(1)], i + 1 if False else i, depth + 1)   # one more trip round the loop
-            i += 1
+            op = l.split()[0]
+            inflight = set().union(*fifo) if fifo else set()
+            if is_ring[i]:
+                dst = regs_of(ring_re.match(l).group(1))
+                if dst & inflight and report and l not in seen:
+                    seen.add(l)
+                    bad.append(f"{name}: `{l}` reloads registers still in flight")
+                fifo.append(dst)
+            elif op == "s_waitcnt":
+                w = re.search(r"vmcnt\((\d+)\)", l)
+                if w:
+                    del fifo[:max(0, len(fifo) - int(w.group(1)))]
+            elif not op.startswith("s_"):
+                hit = regs_of(l[len(op):]) & inflight
+                if hit and report and l not in seen:
+                    seen.add(l)
+                    bad.append(f"{name}: `{l}` touches in-flight ring registers {sorted(hit)[:8]}")
+        return tuple(frozenset(x) for x in fifo)
 
-    walk(0, len(code), 0)
-    if fifo and not any("s_endpgm" in l for l in code[-3:]):
-        bad.append(f"{name}: kernel text does not end in s_endpgm")
+    def merge(a, b):
+        if a is None or a == b:
+            return b if a is None else a
+        # differing histories: keep the longer queue, position-wise union from the young end
+        if len(a) < len(b):
+            a, b = b, a
+        pad = len(a) - len(b)
+        return tuple(a[i] | (b[i - pad] if i >= pad else frozenset()) for i in range(len(a)))
+
+    state_in = {s: None for s in starts}
+    state_in[0] = ()
+    work = [0]
+    rounds = 0
+    while work and rounds < 20000:
+        rounds += 1
+        s = work.pop()
+        out = run_block(s, state_in[s], False)
+        for t in succs(s):
+            m = merge(state_in[t], out)
+            if m != state_in[t]:
+                state_in[t] = m
+                work.append(t)
+    if work:
+        bad.append(f"{name}: dataflow did not converge")
+    for s in starts:
+        if state_in[s] is not None:
+            run_block(s, state_in[s], True)
     return bad
 
 

@@ -106,27 +106,41 @@ __global__ void pack_whh3_kernel(const float* __restrict__ W, u32x4* __restrict_
 // at the back-edge - moves that would copy registers whose data is still in flight.)
 // tools/check_ring_registers.py verifies on the generated ISA that nothing but these loads, the
 // LDS reads of the resident part and the MFMAs ever touches the ring registers.
-template <int UT>
+// AG selects the register file the buffer is pinned to (false: VGPRs, true: AGPRs - both are legal
+// load destinations and MFMA B operands; splitting the ring over the two files keeps the arch
+// VGPRs free for the cell update's VALU work).
+#define VTS_W_LOAD(CONS, REG, VOFF, K)                                                              \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : CONS(REG) : "v"(VOFF), "s"(sbase), "n"((K) * 1024))
+template <int UT, bool AG = false>
 __device__ __forceinline__ void w_issue(u32x4 (&w)[UT], const void* sbase, unsigned voff) {
   static_assert(UT == 2 || UT == 4 || UT == 8, "half-unit of 2, 4 or 8 fragments");
 #pragma unroll
   for (int i = 0; i < UT; ++i) {
-    if (i < 4)
-      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(w[i]) : "v"(voff), "s"(sbase), "n"((i & 3) * 1024));
-    else
-      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"
-                   : "+v"(w[i]) : "v"(voff + 4096u), "s"(sbase), "n"((i & 3) * 1024));
+    const unsigned vo = i < 4 ? voff : voff + 4096u;
+    if constexpr (AG) VTS_W_LOAD("+a", w[i], vo, i & 3);
+    else VTS_W_LOAD("+v", w[i], vo, i & 3);
   }
 }
-template <int N, int UT>
+#undef VTS_W_LOAD
+template <int N, int UT, bool AG = false>
 __device__ __forceinline__ void w_wait(u32x4 (&w)[UT]) {
-  if constexpr (UT == 8)
-    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]),
-                 "+v"(w[6]), "+v"(w[7]) : "n"(N));
-  else if constexpr (UT == 4)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
-  else
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
+  if constexpr (AG) {
+    if constexpr (UT == 8)
+      asm volatile("s_waitcnt vmcnt(%8)" : "+a"(w[0]), "+a"(w[1]), "+a"(w[2]), "+a"(w[3]), "+a"(w[4]), "+a"(w[5]),
+                   "+a"(w[6]), "+a"(w[7]) : "n"(N));
+    else if constexpr (UT == 4)
+      asm volatile("s_waitcnt vmcnt(%4)" : "+a"(w[0]), "+a"(w[1]), "+a"(w[2]), "+a"(w[3]) : "n"(N));
+    else
+      asm volatile("s_waitcnt vmcnt(%2)" : "+a"(w[0]), "+a"(w[1]) : "n"(N));
+  } else {
+    if constexpr (UT == 8)
+      asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]),
+                   "+v"(w[6]), "+v"(w[7]) : "n"(N));
+    else if constexpr (UT == 4)
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+    else
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
+  }
 }
 
 // Arguments as lstm_rec_fwd_kernel.  LDS: h as bf16 planes [buffer 2][hi, lo][16][H], the 16-byte
@@ -307,6 +321,207 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
   w_wait<0, UT>(w2);
 }
 
+// ---- backward -----------------------------------------------------------------------------------
+// Arguments as lstm_rec_bwd_kernel, except that dhlast / dclast are tile16 [Bp, H] (zero rows past
+// B).  dh_rec[16 x H-slice] = dA[16 x 4H] . W_hh[4H x H-slice] with
+// dA split into bf16 planes in LDS ([buffer 2][hi, lo][16][4H], chunk index XOR-ed with the row,
+// k slot = 4*hidden + gate) and the image streamed one k-step (JPW hi + JPW lo fragments) per
+// ring buffer, three k-steps in flight.
+template <int H>
+__global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
+    float* __restrict__ G, const float* __restrict__ cseq, const float* __restrict__ dhseq,
+    const float* __restrict__ dhlast, const float* __restrict__ dclast, float* __restrict__ dbpart,
+    const u32x4* __restrict__ Wp, int B, int T) {
+  using C = RecCfg<H>;
+  using R = Rec3Cfg<H>;
+  constexpr int JPW = C::JPW;
+  constexpr int UT = 2 * JPW;                  // fragments per k-step and wave
+  constexpr int KS = R::KS_B;
+  constexpr bool RING_AG = false;              // register file of the ring buffers
+  static_assert(KS % 4 == 0, "ring of four k-steps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  constexpr int ROWB = 4 * H * 2;              // bytes per row of a plane
+  constexpr int PLANE = 16 * ROWB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int bt = blockIdx.x;
+
+  // running gradients start from the gradients w.r.t. h_T and c_T, given as tile16 blocks
+  f32x4 dc[JPW], dh[JPW];
+  float dbs[JPW][4];
+#pragma unroll
+  for (int jl = 0; jl < JPW; ++jl) {
+    const long blk = ((long)bt * C::JT + wave * JPW + jl) * 256 + lane * 4;
+    dh[jl] = dhlast != nullptr ? *reinterpret_cast<const f32x4*>(dhlast + blk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dc[jl] = dclast != nullptr ? *reinterpret_cast<const f32x4*>(dclast + blk) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dbs[jl][q] = 0.f;
+  }
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(Wp) + (size_t)wave * (KS * UT * 1024);
+  const unsigned voff = lane * 16;
+  auto ks_ptr = [&](int ks) { return wbase + (size_t)(ks * UT) * 1024; };
+
+  auto load_step = [&](f32x4 (&gv)[JPW * 4], f32x4 (&dv)[JPW], int t) {
+    const float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      const int jt = wave * JPW + jl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        gv[jl * 4 + q] = ld_stream(Gt + (long)(q * C::JT + jt) * 256);
+      if (dhseq != nullptr)
+        dv[jl] = ld_stream(dhseq + ((long)(bt * T + t) * C::JT + jt) * 256 + lane * 4);
+      else
+        dv[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto load_cells = [&](f32x4 (&cv)[JPW], int t) {
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      if (t >= 0)
+        cv[jl] = ld_stream(cseq + ((long)(bt * T + t) * C::JT + wave * JPW + jl) * 256 + lane * 4);
+      else
+        cv[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  f32x4 gn[JPW * 4], dn[JPW], cvt[JPW], cvp[JPW];
+  load_step(gn, dn, T - 1);
+  load_cells(cvt, T - 1);
+  load_cells(cvp, T - 2);
+
+  u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
+#pragma unroll
+  for (int i = 0; i < UT; ++i) w0[i] = w1[i] = w2[i] = w3[i] = u32x4{0u, 0u, 0u, 0u};
+  // the whole ring lives in AGPRs: the cell backward needs the arch VGPRs for its VALU operands
+  w_issue<UT, RING_AG>(w0, ks_ptr(0), voff);
+  w_issue<UT, RING_AG>(w1, ks_ptr(1), voff);
+  w_issue<UT, RING_AG>(w2, ks_ptr(2), voff);
+
+  // gate gradients of step t from the running dh / dc: dA to LDS (bf16 planes, buffer t & 1) and
+  // to the gates buffer, bias-gradient partial sums in registers
+  auto cell_bwd = [&](int t) {
+    const int cur = t & 1;
+    float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+    unsigned char* da_s = smem3 + cur * (2 * PLANE);
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      const int jt = wave * JPW + jl;
+      const f32x4 gi = gn[jl * 4 + 0], gf = gn[jl * 4 + 1], gg = gn[jl * 4 + 2], go = gn[jl * 4 + 3];
+      const f32x4 ct = cvt[jl], cp = cvp[jl];
+      const f32x4 dht = dh[jl] + dn[jl];
+      f32x4 dai, daf, dag, dao;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const float tc = fast_tanh(ct[reg]);
+        const float d_o = dht[reg] * tc;
+        const float dcc = dc[jl][reg] + dht[reg] * go[reg] * (1.f - tc * tc);
+        const float d_i = dcc * gg[reg];
+        const float d_g = dcc * gi[reg];
+        const float d_f = dcc * cp[reg];
+        dc[jl][reg] = dcc * gf[reg];
+        dai[reg] = d_i * gi[reg] * (1.f - gi[reg]);
+        daf[reg] = d_f * gf[reg] * (1.f - gf[reg]);
+        dag[reg] = d_g * (1.f - gg[reg] * gg[reg]);
+        dao[reg] = d_o * go[reg] * (1.f - go[reg]);
+        // the four gates of (window 4g+reg, hidden jt*16+r) are four consecutive k slots: 8 bytes
+        // per plane
+        uint2 hi, lo;
+        split4(dai[reg], daf[reg], dag[reg], dao[reg], hi, lo);
+        const int row = 4 * g + reg;
+        const int j = jt * 16 + r;
+        const int off = row * ROWB + ((((j >> 1) ^ (row & 15)) << 4) | ((j & 1) << 3));
+        *reinterpret_cast<uint2*>(da_s + off) = hi;
+        *reinterpret_cast<uint2*>(da_s + PLANE + off) = lo;
+      }
+      dbs[jl][0] += (dai[0] + dai[1]) + (dai[2] + dai[3]);
+      dbs[jl][1] += (daf[0] + daf[1]) + (daf[2] + daf[3]);
+      dbs[jl][2] += (dag[0] + dag[1]) + (dag[2] + dag[3]);
+      dbs[jl][3] += (dao[0] + dao[1]) + (dao[2] + dao[3]);
+      st_stream(Gt + (long)(0 * C::JT + jt) * 256, dai);
+      st_stream(Gt + (long)(1 * C::JT + jt) * 256, daf);
+      st_stream(Gt + (long)(2 * C::JT + jt) * 256, dag);
+      st_stream(Gt + (long)(3 * C::JT + jt) * 256, dao);
+      // one hidden tile at a time: interleaving the four tiles' arithmetic quadruples the
+      // temporaries live at once, and this kernel has no registers to spare
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Loop shape: [product of step t+1 -> dh][cell backward of step t], the first cell backward
+  // peeled off.  One loop exit and no branch around the product: any other shape lets the
+  // compiler reconcile the ring buffers' registers with moves while their loads are in flight.
+  cell_bwd(T - 1);
+  for (int t = T - 2; t >= 0; --t) {
+    // saved tensors of step t: in flight during the product below
+    load_step(gn, dn, t);
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) cvt[jl] = cvp[jl];
+    load_cells(cvp, t - 1);
+    lds_barrier();
+    const unsigned char* da_s = smem3 + ((t + 1) & 1) * (2 * PLANE);
+    f32x4 acc[JPW];
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) acc[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto lds_a = [&](int plane, int ks) {
+      return *reinterpret_cast<const u32x4*>(da_s + plane * PLANE + r * ROWB + (((4 * ks + g) ^ r) << 4));
+    };
+    u32x4 ah = lds_a(0, 0), al = lds_a(1, 0);
+    // one k-step: fragments w[0..JPW) = hi, w[JPW..2*JPW) = lo of this wave's JPW output tiles
+    auto kstep = [&](u32x4 (&w)[UT], int ks) {
+      const int kn = (ks + 1) & (KS - 1);
+      const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);
+      w_wait<3 * UT, UT, RING_AG>(w);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl)
+        acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), as_bf16x8(w[jl]), acc[jl], 0, 0, 0);
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl)
+        acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(w[JPW + jl]), acc[jl], 0, 0, 0);
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl)
+        acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(w[jl]), acc[jl], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ah = nh;
+      al = nl;
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ks += 4) {
+      w_issue<UT, RING_AG>(w3, ks_ptr(ks + 3), voff);
+      kstep(w0, ks);
+      w_issue<UT, RING_AG>(w0, ks_ptr((ks + 4) & (KS - 1)), voff);
+      kstep(w1, ks + 1);
+      w_issue<UT, RING_AG>(w1, ks_ptr((ks + 5) & (KS - 1)), voff);
+      kstep(w2, ks + 2);
+      w_issue<UT, RING_AG>(w2, ks_ptr((ks + 6) & (KS - 1)), voff);
+      kstep(w3, ks + 3);
+    }
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) dh[jl] = acc[jl];
+    cell_bwd(t);
+  }
+  // keep the wrapped-around ring loads' registers live until they have landed (see the forward kernel)
+  w_wait<0, UT, RING_AG>(w0);
+  w_wait<0, UT, RING_AG>(w1);
+  w_wait<0, UT, RING_AG>(w2);
+
+  // bias-gradient partials: sum over the 4 row groups (lanes r, r+16, r+32, r+48)
+#pragma unroll
+  for (int jl = 0; jl < JPW; ++jl) {
+    const int jt = wave * JPW + jl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = dbs[jl][q];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (g == 0) dbpart[(long)bt * (4 * H) + q * H + jt * 16 + r] = s;
+    }
+  }
+}
+
 template <int H>
 int run_fwd3(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B,
              int T, hipStream_t stream) {
@@ -331,6 +546,30 @@ int run_fwd3(float* G, float* cseq, float* hseq, float* hlast, float* clast, con
   return VTS_OK;
 }
 
+template <int H>
+int run_bwd3(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+             float* dbpart, const float* W_hh, float* Wp, int B, int T, hipStream_t stream) {
+  using C = RecCfg<H>;
+  using R = Rec3Cfg<H>;
+  u32x4* img = reinterpret_cast<u32x4*>(Wp);
+  hipLaunchKernelGGL((pack_whh3_kernel<H, true>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
+  VTS_CHECK_LAUNCH("pack_whh3_bwd");
+  static bool attr_set = false;
+  if (!attr_set && R::LDS_B > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec3_bwd_kernel<H>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_B);
+    if (e != hipSuccess) {
+      vts_set_error("lstm_rec3_bwd: cannot reserve %zu B of LDS: %s", R::LDS_B, hipGetErrorString(e));
+      return VTS_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_rec3_bwd_kernel<H>, dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_B, stream, G, cseq, dhseq,
+                     dhlast, dclast, dbpart, img, B, T);
+  VTS_CHECK_LAUNCH("lstm_rec3_bwd");
+  return VTS_OK;
+}
+
 }  // namespace
 
 bool vts_lstm_rec3_supported(int H) { return H == 64 || H == 128 || H == 256; }
@@ -341,6 +580,17 @@ int vts_lstm_rec3_fwd(float* G, float* cseq, float* hseq, float* hlast, float* c
     case 64: return run_fwd3<64>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
     case 128: return run_fwd3<128>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
     case 256: return run_fwd3<256>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+  }
+  vts_set_error("lstm bf16x3 recurrence: hidden size %d not supported (64, 128, 256)", H);
+  return VTS_ERR_UNSUPPORTED;
+}
+
+int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+                      float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream) {
+  switch (H) {
+    case 64: return run_bwd3<64>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+    case 128: return run_bwd3<128>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+    case 256: return run_bwd3<256>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
   }
   vts_set_error("lstm bf16x3 recurrence: hidden size %d not supported (64, 128, 256)", H);
   return VTS_ERR_UNSUPPORTED;

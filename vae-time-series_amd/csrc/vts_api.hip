@@ -22,6 +22,8 @@ int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, flo
                        int M, int N, int K, int accumulate, hipStream_t stream);
 bool vts_lstm_hidden_supported(int H);
 bool vts_lstm_rec3_supported(int H);
+int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+                      float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream);
 int vts_lstm_rec3_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
                       int B, int T, int H, hipStream_t stream);
 int vts_lstm_rec_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B, int T,
@@ -113,9 +115,14 @@ size_t vts_lstm_seqgrad_bytes(int64_t B, int64_t T, int64_t F) { return (size_t)
 
 // workspace of the recurrent kernels: packed W_hh image + per-batch-tile bias partials
 static size_t rec_ws_pack_bytes(int64_t H) { return round256((size_t)4 * H * H * sizeof(float)); }
+static size_t rec_ws_dbpart_bytes(int64_t B, int64_t H) {
+  return round256((size_t)(pad16(B) / 16) * 4 * H * sizeof(float));
+}
+static size_t rec_ws_seed_bytes(int64_t B, int64_t H) { return round256((size_t)pad16(B) * H * sizeof(float)); }
+// [packed W_hh image][bias-gradient partials][dh_T in tile16 order][dc_T in tile16 order]
 size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
   (void)T;
-  return rec_ws_pack_bytes(H) + round256((size_t)(pad16(B) / 16) * 4 * H * sizeof(float));
+  return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H);
 }
 size_t vts_lstm_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t F, int64_t H) {
   const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T, 0);   // mode 0 splits the most
@@ -182,7 +189,17 @@ int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq
   float* wpack = reinterpret_cast<float*>(workspace);
   float* dbpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + rec_ws_pack_bytes(H));
   const int nbt = (int)(pad16(B) / 16);
-  VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
+  if (dtype_mode == 1 && vts_lstm_rec3_supported((int)H)) {
+    // the bf16x3 kernel takes the gradients w.r.t. h_T / c_T as tile16 blocks (one coalesced load
+    // per accumulator tile instead of per-lane row gathers inside a register-bound kernel)
+    char* seed = reinterpret_cast<char*>(dbpart) + rec_ws_dbpart_bytes(B, H);
+    float* seed_h = dh_last ? reinterpret_cast<float*>(seed) : nullptr;
+    float* seed_c = dc_last ? reinterpret_cast<float*>(seed + rec_ws_seed_bytes(B, H)) : nullptr;
+    if (seed_h) VTS_RC(vts_ew_tile16_convert(dh_last, seed_h, (int)B, 1, (int)H, 0, st));
+    if (seed_c) VTS_RC(vts_ew_tile16_convert(dc_last, seed_c, (int)B, 1, (int)H, 0, st));
+    VTS_RC(vts_lstm_rec3_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
+  } else
+    VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
   if (db_ih) VTS_RC(vts_colsum_partials(dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));
   if (db_hh) VTS_RC(vts_colsum_partials(dbpart, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
   return VTS_OK;
