@@ -17,6 +17,7 @@
 // m' = (bt*T + t)*16 + bi  <->  window b = bt*16 + bi at step t (+ tshift), memory row b*T + t.
 // Rows with b >= B or a shifted step outside [0, T) read as zero.
 #include "vts_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -402,16 +403,32 @@ __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmP
 // contiguous, 80-byte row pitch) in two planes (hi, lo) per operand; the C/D layout of the 16x16
 // bf16 MFMA equals the f32 one, so mapping and epilogue are shared with the f32 kernel.
 constexpr int BK3 = 32;                 // k elements per main-loop iteration
-constexpr int ROWB = 80;                // LDS row pitch in bytes (32 bf16 + 16 B pad)
+constexpr int ROWB = 64;                // LDS row pitch in bytes (32 bf16, no padding)
 constexpr int PLANE = 128 * ROWB;       // one plane (hi or lo) of one operand tile
+
+// Byte offset of (row, byte kbyte of the row's 64) inside a plane.  Rows are 64 bytes = 16 banks, so
+// an unswizzled tile maps rows r, r+4, r+8, ... onto the same banks.  Two XORs spread them:
+//   the row's low two bits        ^= bits 4-5 of the row   (separates rows 16 apart)
+//   the 16-byte chunk of the row  ^= bits 2-3 of the row   (separates rows 4 apart)
+// With it the MFMA fragment reads (16 consecutive rows, one chunk, 16 bytes per lane) touch every
+// bank once, and the stores of all four operand kinds (row-pair halves, 4-row columns of 8
+// bytes, tile16 blocks either way round) hit each bank the minimum number of times or twice that.
+__device__ __forceinline__ int lds3_off(int row, int kbyte) {
+  const int prow = (row & ~3) | ((row & 3) ^ ((row >> 4) & 3));
+  return prow * ROWB + ((((kbyte >> 4) ^ ((row >> 2) & 3)) << 4) | (kbyte & 15));
+}
 #ifndef VTS_GEMM3_NSUB
 #define VTS_GEMM3_NSUB 1
 #endif
+#ifndef VTS_GEMM3_PIPE
+#define VTS_GEMM3_PIPE 0
+#endif
 #ifndef VTS_GEMM3_WPS
-#define VTS_GEMM3_WPS 3
+#define VTS_GEMM3_WPS (VTS_GEMM3_PIPE ? 2 : 3)
 #endif
 constexpr int NSUB3 = VTS_GEMM3_NSUB;   // 32-deep k sub-chunks staged per barrier pair
-constexpr size_t GEMM3_LDS_BYTES = 4ul * PLANE * NSUB3;   // per sub-chunk: A hi, A lo, B hi, B lo
+constexpr bool PIPE3 = VTS_GEMM3_PIPE;  // software-pipelined k loop (two LDS buffers) or one buffer and more workgroups per CU
+constexpr size_t GEMM3_LDS_BYTES = (PIPE3 ? 2ul : 1ul) * 4ul * PLANE * NSUB3;   // per buffer: A hi, A lo, B hi, B lo
 
 __device__ __forceinline__ void load4(const float* __restrict__ p, int nvalid, float (&v)[4]) {
   if (nvalid >= 4) {
@@ -479,41 +496,136 @@ __device__ __forceinline__ void load3(const GemmParams& P, bool is_a, const floa
   }
 }
 
-// Split and write the 16 values into the hi / lo planes of the operand's LDS tile.
+// Per-thread streaming state of one operand for the interior of the k loop: everything that does
+// not change from one 32-deep k-step to the next (row validity, base pointers, strides) is worked
+// out once, so that a full k-step costs four 16-byte loads and a pointer bump.  load3 above stays
+// the path for the last, partial k-step and for threads on the ragged edge of the matrix.
 template <int OPK>
-__device__ __forceinline__ void store3(char* __restrict__ hi, char* __restrict__ lo, int tid, const float (&v)[4][4]) {
-  if constexpr (OPK == 0) {          // v[s][i] = (row tid>>1, k = 16*(tid&1) + 4s + i)
-    const int off = (tid >> 1) * ROWB + (tid & 1) * 32;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint2 h, l;
-      split4(v[s][0], v[s][1], v[s][2], v[s][3], h, l);
-      *reinterpret_cast<uint2*>(hi + off + 8 * s) = h;
-      *reinterpret_cast<uint2*>(lo + off + 8 * s) = l;
+struct Stream3 {
+  const float* p = nullptr;   // next k-step's first element for this thread (nullptr: contributes zeros)
+  long step = 0;              // elements between consecutive k-steps
+  long ld = 0;                // OPK 1: row stride
+  int nv = 4;                 // OPK 1: valid elements of this thread's 4-wide row pieces (N % 4 != 0 edge)
+  // OPK 1 with the window-row mapping: position of this thread's 16-row group
+  bool map = false;
+  int T = 1, Bwin = 0, tshift = 0, tile = 0, t = 0, bi = 0;
+  const float* base = nullptr;
+  int rr = 0;
+
+  __device__ __forceinline__ void init(const GemmParams& P, bool is_a, const float* rowptr, int r0, int kbeg, int tid) {
+    const float* b = is_a ? P.A : P.B;
+    ld = is_a ? P.lda : P.ldb;
+    const int R = is_a ? P.M : P.N;
+    if constexpr (OPK == 0) {
+      p = rowptr ? rowptr + kbeg + (tid & 1) * 16 : nullptr;
+      step = BK3;
+    } else if constexpr (OPK == 1) {
+      rr = r0 + (tid & 31) * 4;
+      nv = min(4, max(0, R - rr));
+      map = !is_a && P.b_map;
+      const int k = kbeg + (tid >> 5) * 4;
+      base = b;
+      if (map) {
+        T = P.T; Bwin = P.Bwin; tshift = P.b_tshift;
+        bi = k & 15;
+        tile = (k >> 4) / T;
+        t = (k >> 4) % T;
+      } else {
+        p = nv > 0 ? b + (long)k * ld + rr : nullptr;
+        step = (long)BK3 * ld;
+      }
+    } else if constexpr (OPK == 2) {
+      const int blk = tid >> 4;
+      const int rt = (r0 >> 4) + (blk >> 1), kt = (kbeg >> 4) + (blk & 1);
+      if (rt * 16 < R) p = b + ((long)rt * (P.K >> 4) + kt) * 256 + (((tid & 15) >> 2) * 16 + 4 * (tid & 3)) * 4;
+      step = 2 * 256;
+    } else {
+      const int blk = tid >> 4;
+      const int kt = (kbeg >> 4) + (blk >> 3), rt = (r0 >> 4) + (blk & 7);
+      if (rt * 16 < R) p = b + ((long)kt * (R >> 4) + rt) * 256 + (((tid & 15) >> 2) * 16 + 4 * (tid & 3)) * 4;
+      step = 2L * (R >> 4) * 256;
     }
+  }
+
+  // one full k-step (all 32 k inside the slice); v as load3 fills it
+  __device__ __forceinline__ void load_full(float (&v)[4][4]) {
+    const float* q = p;
+    long rs = 4;                     // distance between the four 16-byte pieces
+    if constexpr (OPK == 1) {
+      rs = ld;
+      if (map) {
+        // rows b = tile*16 + bi + s of time slice t (+ tshift): all four in range, or zeros
+        const int tt = t + tshift;
+        const bool ok = nv > 0 && tt >= 0 && tt < T && (tile * 16 + bi + 4 <= Bwin);
+        q = ok ? base + ((long)(tile * 16 + bi) * T + tt) * ld + rr : nullptr;
+        rs = (long)T * ld;
+      }
+    }
+    if (q != nullptr && (OPK != 1 || nv == 4)) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f32x4_u x = *reinterpret_cast<const f32x4_u*>(q + s * rs);
+        v[s][0] = x[0]; v[s][1] = x[1]; v[s][2] = x[2]; v[s][3] = x[3];
+      }
+    } else if (q != nullptr) {       // the one thread whose piece crosses the last column
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[s][i] = (i < nv) ? q[s * rs + i] : 0.f;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f;
+    }
+  }
+  __device__ __forceinline__ void advance() {
+    if constexpr (OPK == 1) {
+      if (map) {                     // 32 logical rows further: two time slices of the same 16 windows
+        t += 2;
+        if (t >= T) { t -= T; ++tile; }
+        return;
+      }
+    }
+    if (p != nullptr) p += step;
+  }
+  // the mapped rows of a group straddle the batch end: take the checked path for that k-step
+  __device__ __forceinline__ bool ragged() const {
+    if constexpr (OPK == 1) return map && (tile * 16 + 16 > Bwin) && (tile * 16 < Bwin);
+    return false;
+  }
+};
+
+// Split and write four of the thread's 16 values (chunk c = 0..3) into the hi / lo planes of the
+// operand's LDS tile; the four chunks together cover the tile.  Chunked so that the caller can
+// spread the conversion work between MFMAs.
+template <int OPK>
+__device__ __forceinline__ void store3_chunk(char* __restrict__ hi, char* __restrict__ lo, int tid,
+                                             const float (&v)[4][4], int c) {
+  uint2 h, l;
+  if constexpr (OPK == 0) {          // v[s][i] = (row tid>>1, k = 16*(tid&1) + 4s + i)
+    const int off = lds3_off(tid >> 1, (tid & 1) * 32 + 8 * c);
+    split4(v[c][0], v[c][1], v[c][2], v[c][3], h, l);
+    *reinterpret_cast<uint2*>(hi + off) = h;
+    *reinterpret_cast<uint2*>(lo + off) = l;
   } else if constexpr (OPK == 1 || OPK == 2) {   // v[s][i] = (row base + i, k = kbase + s)
     int rowb, kbyte;
     if constexpr (OPK == 1) { rowb = (tid & 31) * 4; kbyte = (tid >> 5) * 8; }
     else { const int blk = tid >> 4; rowb = (blk >> 1) * 16 + ((tid & 15) >> 2) * 4; kbyte = ((blk & 1) * 16 + (tid & 3) * 4) * 2; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint2 h, l;
-      split4(v[0][i], v[1][i], v[2][i], v[3][i], h, l);
-      *reinterpret_cast<uint2*>(hi + (rowb + i) * ROWB + kbyte) = h;
-      *reinterpret_cast<uint2*>(lo + (rowb + i) * ROWB + kbyte) = l;
-    }
+    split4(v[0][c], v[1][c], v[2][c], v[3][c], h, l);
+    *reinterpret_cast<uint2*>(hi + lds3_off(rowb + c, kbyte)) = h;
+    *reinterpret_cast<uint2*>(lo + lds3_off(rowb + c, kbyte)) = l;
   } else {                           // v[s][i] = (row base + s, k = kbase + i)
     const int blk = tid >> 4;
     const int rowb = (blk & 7) * 16 + (tid & 3) * 4;
     const int kbyte = ((blk >> 3) * 16 + ((tid & 15) >> 2) * 4) * 2;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint2 h, l;
-      split4(v[s][0], v[s][1], v[s][2], v[s][3], h, l);
-      *reinterpret_cast<uint2*>(hi + (rowb + s) * ROWB + kbyte) = h;
-      *reinterpret_cast<uint2*>(lo + (rowb + s) * ROWB + kbyte) = l;
-    }
+    split4(v[c][0], v[c][1], v[c][2], v[c][3], h, l);
+    *reinterpret_cast<uint2*>(hi + lds3_off(rowb + c, kbyte)) = h;
+    *reinterpret_cast<uint2*>(lo + lds3_off(rowb + c, kbyte)) = l;
   }
+}
+template <int OPK>
+__device__ __forceinline__ void store3(char* __restrict__ hi, char* __restrict__ lo, int tid, const float (&v)[4][4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) store3_chunk<OPK>(hi, lo, tid, v, c);
 }
 
 template <int AK> struct OpKindA { static constexpr int v = (AK == A_ROW) ? 0 : (AK == A_COL) ? 1 : (AK == A_T16) ? 2 : 3; };
@@ -544,49 +656,102 @@ __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const G
   if constexpr (AK == A_ROW) arow = a_row_base(P, m0, tid);
   if constexpr (BKIND == B_NK) brow = b_row_base(P, n0, tid);
 
-  float va[NSUB3][4][4], vb[NSUB3][4][4];
-  auto stage_load = [&](int k0) {
-#pragma unroll
-    for (int u = 0; u < NSUB3; ++u) {
-      load3<OA>(P, true, arow, m0, k0 + u * BK3, kend, tid, va[u]);
-      load3<OB>(P, false, brow, n0, k0 + u * BK3, kend, tid, vb[u]);
-    }
+  static_assert(NSUB3 == 1, "the pipeline below assumes one 32-deep chunk per step");
+  // raw fp32 values of two tiles in flight: tile j lives in register set j & 1
+  float va[2][4][4], vb[2][4][4];
+  Stream3<OA> sa;
+  Stream3<OB> sb;
+  sa.init(P, true, arow, m0, kbeg, tid);
+  sb.init(P, false, brow, n0, kbeg, tid);
+  // k0 .. k0+31 entirely inside the slice: unchecked loads, except for threads on a ragged edge
+  auto stage_load = [&](int k0, float (&ra)[4][4], float (&rb)[4][4]) {
+    const bool full = k0 + BK3 <= kend;
+    if (full && !sa.ragged()) sa.load_full(ra);
+    else load3<OA>(P, true, arow, m0, k0, kend, tid, ra);
+    if (full && !sb.ragged()) sb.load_full(rb);
+    else load3<OB>(P, false, brow, n0, k0, kend, tid, rb);
+    sa.advance();
+    sb.advance();
   };
-  auto stage_store = [&]() {
-#pragma unroll
-    for (int u = 0; u < NSUB3; ++u) {
-      char* base = lds3 + u * 4 * PLANE;
-      store3<OA>(base, base + PLANE, tid, va[u]);
-      store3<OB>(base + 2 * PLANE, base + 3 * PLANE, tid, vb[u]);
-    }
-  };
+  // Software pipeline over 32-deep k-steps, two LDS buffers, two register sets, one barrier per step:
+  //   step kt:  global loads of tile kt+2 -> register set kt&1   (a whole step ahead of their use)
+  //             MFMAs on LDS buffer kt&1   ||   split + store of tile kt+1 (register set (kt+1)&1)
+  //             into LDS buffer (kt+1)&1
+  // The conversion VALU work and the LDS stores have no dependence on the step's MFMAs, so they
+  // issue in the shadow of the matrix pipe (a 16x16x32 MFMA occupies it for 16 cycles but takes
+  // one issue slot).  The barrier orders LDS only: a full __syncthreads() would also drain the
+  // loads in flight.
   const int nk = (kend - kbeg + BKL - 1) / BKL;
   if (nk > 0) {
-    stage_load(kbeg);
-    stage_store();
+    stage_load(kbeg, va[0], vb[0]);
+    store3<OA>(lds3, lds3 + PLANE, tid, va[0]);
+    store3<OB>(lds3 + 2 * PLANE, lds3 + 3 * PLANE, tid, vb[0]);
+    if (nk > 1) stage_load(kbeg + BKL, va[1], vb[1]);
   }
-  __syncthreads();
-  const int a_off = (wm * 64 + r) * ROWB + g * 16;
-  const int b_off = (wn * 64 + r) * ROWB + g * 16;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) stage_load(kbeg + (kt + 1) * BKL);
+  vts_lds_barrier();
+  int a_off[4], b_off[4];               // this lane's fragment of each of the wave's 4 + 4 row blocks
 #pragma unroll
-    for (int u = 0; u < NSUB3; ++u) {
-      const char* a_hi = lds3 + u * 4 * PLANE;
-      const char* a_lo = a_hi + PLANE;
-      const char* b_hi = a_hi + 2 * PLANE;
-      const char* b_lo = a_hi + 3 * PLANE;
+  for (int i = 0; i < 4; ++i) {
+    a_off[i] = lds3_off(wm * 64 + i * 16 + r, g * 16);
+    b_off[i] = lds3_off(wn * 64 + i * 16 + r, g * 16);
+  }
+  auto step = [&](int kt, auto par) {
+    constexpr int PAR = decltype(par)::value;         // kt & 1
+    if (kt + 2 < nk) stage_load(kbeg + (kt + 2) * BKL, va[PAR], vb[PAR]);
+    const char* a_hi = lds3 + PAR * 4 * PLANE;
+    const char* a_lo = a_hi + PLANE;
+    const char* b_hi = a_hi + 2 * PLANE;
+    const char* b_lo = a_hi + 3 * PLANE;
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + a_off[i]);
+      al[i] = *reinterpret_cast<const bf16x8*>(a_lo + a_off[i]);
+      bh[i] = *reinterpret_cast<const bf16x8*>(b_hi + b_off[i]);
+      bl[i] = *reinterpret_cast<const bf16x8*>(b_lo + b_off[i]);
+    }
+    // 48 MFMAs in 16 groups of three (one accumulator tile each); after every second group one
+    // eighth of the next tile's conversion (12 VALU, 2 LDS stores) issues in the matrix pipe's
+    // shadow.  sched_barrier(0) pins that order.  The stores are unconditional: on the last step
+    // they re-store stale registers into the idle buffer, which keeps this block branch-free.
+    char* nbase = lds3 + (1 - PAR) * 4 * PLANE;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = q & 3, j = q >> 2;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      if (q & 1) {
+        const int c = q >> 1;          // 0..7: four chunks of A, then four of B
+        if (c < 4) store3_chunk<OA>(nbase, nbase + PLANE, tid, va[1 - PAR], c);
+        else store3_chunk<OB>(nbase + 2 * PLANE, nbase + 3 * PLANE, tid, vb[1 - PAR], c - 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    vts_lds_barrier();
+  };
+  if constexpr (PIPE3) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
+    // One LDS buffer: the next tile's loads fly during the MFMAs, its conversion and stores sit
+    // between two barriers.  Latency is hidden by the other workgroups of the CU (3 resident)
+    // rather than inside the wave.
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more && kt > 0) stage_load(kbeg + (kt + 1) * BKL, va[1], vb[1]);
       bf16x8 ah[4], al[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + a_off + i * 16 * ROWB);
-        al[i] = *reinterpret_cast<const bf16x8*>(a_lo + a_off + i * 16 * ROWB);
+        ah[i] = *reinterpret_cast<const bf16x8*>(lds3 + a_off[i]);
+        al[i] = *reinterpret_cast<const bf16x8*>(lds3 + PLANE + a_off[i]);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b_hi + b_off + j * 16 * ROWB);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b_lo + b_off + j * 16 * ROWB);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds3 + 2 * PLANE + b_off[j]);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(lds3 + 3 * PLANE + b_off[j]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
@@ -594,10 +759,13 @@ __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const G
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
         }
       }
+      vts_lds_barrier();           // every wave is done reading this k chunk
+      if (more) {
+        store3<OA>(lds3, lds3 + PLANE, tid, va[1]);
+        store3<OB>(lds3 + 2 * PLANE, lds3 + 3 * PLANE, tid, vb[1]);
+      }
+      vts_lds_barrier();
     }
-    __syncthreads();           // every wave is done reading this k chunk
-    if (more) stage_store();
-    __syncthreads();
   }
   epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane);
 }

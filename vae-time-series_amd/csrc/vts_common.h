@@ -46,6 +46,14 @@ __host__ __device__ static inline long vts_tile16_offset(long m, long n, long N)
   return ((m >> 4) * (N >> 4) + (n >> 4)) * 256 + ((((m & 15) >> 2) * 16 + (n & 15)) << 2) + (m & 3);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store (vmcnt(0)), which drains prefetches issued before it.
+static __device__ __forceinline__ void vts_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- bf16x3 operand split ----------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
