@@ -243,6 +243,15 @@ def main():
                         "algorithmic_frac_of_f32_mfma_peak": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4),
                         "note": "achieved = executed bf16 matrix-core FLOPs (3 per algorithmic fp32 FLOP) / "
                                 "kernel time, against the dense bf16 peak"}
+        # HBM bytes per launch of the dominant kernel, from the committed PMC passes (same shape only)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+            key = {"lstm_recurrent_bwd": "lstm_rec3_bwd_kernel<256>", "lstm_recurrent_fwd": "lstm_rec3_fwd_kernel<256>"}.get(dom)
+            if a.mode == "bf16x3" and (a.batch, a.T, a.H) == (4096, 96, 256) and key in pmc:
+                roofline["traffic"] = pmc[key]["hbm_bytes"]
+                roofline["traffic_note"] = "HBM bytes per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_hbm_traffic.json)"
+        except (OSError, KeyError, ValueError):
+            pass
         # The recurrent kernels re-read the packed W_hh image (4*H*H*4 bytes, L2-resident) once per
         # time step and workgroup; with the matrix-core time cut to 3/16 that stream is what bounds them.
         l2 = {}

@@ -15,7 +15,8 @@
  *    1 = "bf16x3": each fp32 operand is split into a bf16 head and a bf16 tail while it is staged,
  *    the product is head*head + head*tail + tail*head on the bf16 matrix cores with fp32
  *    accumulation (error ~2^-16 per product, inside the 1e-4 parity bound).  The recurrent
- *    kernels always compute in fp32.  Other values are rejected.
+ *    entry points follow the mode for H >= 64 and use the fp32 kernels below that.  Other values
+ *    are rejected.
  *
  * Layouts
  *  - sequences are batch-first row-major [B, T, F] exactly as the reference feeds nn.LSTM;

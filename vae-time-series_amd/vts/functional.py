@@ -19,12 +19,13 @@ _MODE = 0  # dtype_mode of the C ABI passed to the LSTM GEMM stages
 
 
 def set_mode(name: str) -> None:
-    """Arithmetic of the LSTM's dense products (input projection, data and weight gradients):
+    """Arithmetic of the LSTM's dense products (input projection, recurrent product, data and
+    weight gradients):
     "f32"    - exact fp32 on the f32 matrix cores (v_mfma_f32_16x16x4_f32);
     "bf16x3" - each fp32 operand split into two bf16 values, three bf16 MFMAs per product with
                fp32 accumulation: fp32-level accuracy (~2^-16 relative per product) at a
-               fraction of the f32 MFMA cost.
-    The recurrence, heads, reparameterisation and ELBO are fp32 in both modes."""
+               fraction of the f32 MFMA cost.  Hidden sizes below 64 keep the fp32 recurrence.
+    The cell update, heads, reparameterisation and ELBO are fp32 in both modes."""
     global _MODE
     _MODE = MODES[name]
 
