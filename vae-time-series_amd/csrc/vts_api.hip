@@ -105,7 +105,7 @@ static bool fits_int(int64_t v) { return v >= 0 && v < (int64_t)2147483647; }
 
 extern "C" {
 
-const char* vts_version(void) { return "vts-hip 0.1 (gfx950, fp32 mfma)"; }
+const char* vts_version(void) { return "vts-hip 0.2 (gfx950, fp32 + bf16x3 mfma)"; }
 const char* vts_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------ LSTM
