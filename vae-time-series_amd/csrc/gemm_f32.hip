@@ -440,22 +440,43 @@ __device__ __forceinline__ void load4(const float* __restrict__ p, int nvalid, f
   }
 }
 
-// 16 fp32 values per thread for one 128 x 32 operand tile; v[s][i], meaning depends on the kind
-// (see store3).  OPK: 0 = k-contiguous rows (A_ROW, B_NK), 1 = row-contiguous (A_COL, B_KN),
-// 2 = tile16 [rows, K] (A_T16), 3 = tile16 [K, rows] (A_T16T).
+// Row pointer of logical row `row` of a k-contiguous operand (A_ROW with the optional window-row
+// mapping, or B_NK), or nullptr when the row is outside the matrix.
+__device__ __forceinline__ const float* row_ptr3(const GemmParams& P, bool is_a, int row) {
+  if (is_a) {
+    bool valid = row < P.M;
+    long rr = row;
+    if (P.a_map && valid) rr = window_row(row, P.T, P.Bwin, P.a_tshift, valid);
+    return valid ? P.A + rr * P.lda : nullptr;
+  }
+  return (row < P.N) ? P.B + (long)row * P.ldb : nullptr;
+}
+
+// 16 fp32 values per thread for one 128 x 32 operand tile as four 16-byte pieces v[c][0..3]; every
+// piece is one load instruction, and the lane -> address maps are chosen so that an instruction's
+// 64 lanes read whole cache lines (a strided map costs several hundred cycles of issue
+// back-pressure per instruction).  OPK:
+//  0 = k-contiguous rows (A_ROW, B_NK): row tid/2, piece c = k 16*(tid%2) + 4c..+3 (64 contiguous
+//      bytes per thread; a lane-contiguous map measured slower here: it needs four window-row
+//      pointers per thread in the prologue of a kernel whose k loop is only 8-12 steps long);
+//  1 = row-contiguous (A_COL, B_KN): piece c = k row 4*(tid/32) + c, rows 4*(tid%32)..+3
+//      (32 lanes x 16 B contiguous);
+//  2 = tile16 [rows, K] (A_T16): piece c = slot 16*g + 4*cq + c of block tid/16 (see store3);
+//  3 = tile16 [K, rows] (A_T16T): piece c = block 4*wave + c, slot lane (one whole 1 KiB block
+//      per instruction): k = 4*(lane/16)..+3 of row lane%16.
 template <int OPK>
-__device__ __forceinline__ void load3(const GemmParams& P, bool is_a, const float* rowptr, int r0, int k0, int kend,
-                                      int tid, float (&v)[4][4]) {
+__device__ __forceinline__ void load3(const GemmParams& P, bool is_a, const float* const (&rows)[4], int r0, int k0,
+                                      int kend, int tid, float (&v)[4][4]) {
   const float* base = is_a ? P.A : P.B;
   const long ld = is_a ? P.lda : P.ldb;
   const int R = is_a ? P.M : P.N;          // extent of the row (m or n) index
   if constexpr (OPK == 0) {
     const int k = k0 + (tid & 1) * 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int nv = (rowptr != nullptr) ? min(4, kend - (k + 4 * s)) : 0;
-      if (nv > 0) load4(rowptr + k + 4 * s, nv, v[s]);
-      else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f; }
+    for (int c = 0; c < 4; ++c) {
+      const int nv = (rows[0] != nullptr) ? min(4, kend - (k + 4 * c)) : 0;
+      if (nv > 0) load4(rows[0] + k + 4 * c, nv, v[c]);
+      else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
     }
   } else if constexpr (OPK == 1) {
     const int rr = r0 + (tid & 31) * 4;
@@ -483,15 +504,14 @@ __device__ __forceinline__ void load3(const GemmParams& P, bool is_a, const floa
       else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f; }
     }
   } else {
-    const int blk = tid >> 4;
-    const int kt = (k0 >> 4) + (blk >> 3), rt = (r0 >> 4) + (blk & 7);
-    const int g = (tid & 15) >> 2, cq = tid & 3;
-    const bool valid = (rt * 16 < R) && (kt * 16 < kend);
-    const float* p = base + ((long)kt * (R >> 4) + rt) * 256 + (g * 16 + 4 * cq) * 4;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int kt = (k0 >> 4) + (wave >> 1);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (valid) load4(p + 4 * s, 4, v[s]);
-      else { v[s][0] = v[s][1] = v[s][2] = v[s][3] = 0.f; }
+    for (int c = 0; c < 4; ++c) {
+      const int rt = (r0 >> 4) + 4 * (wave & 1) + c;
+      const bool valid = (rt * 16 < R) && (kt * 16 < kend);
+      if (valid) load4(base + ((long)kt * (R >> 4) + rt) * 256 + lane * 4, 4, v[c]);
+      else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
     }
   }
 }
@@ -503,6 +523,7 @@ __device__ __forceinline__ void load3(const GemmParams& P, bool is_a, const floa
 template <int OPK>
 struct Stream3 {
   const float* p = nullptr;   // next k-step's first element for this thread (nullptr: contributes zeros)
+  const float* rows[4] = {nullptr, nullptr, nullptr, nullptr};   // OPK 0: rows[0] = this thread's row
   long step = 0;              // elements between consecutive k-steps
   long ld = 0;                // OPK 1: row stride
   int nv = 4;                 // OPK 1: valid elements of this thread's 4-wide row pieces (N % 4 != 0 edge)
@@ -512,12 +533,13 @@ struct Stream3 {
   const float* base = nullptr;
   int rr = 0;
 
-  __device__ __forceinline__ void init(const GemmParams& P, bool is_a, const float* rowptr, int r0, int kbeg, int tid) {
+  __device__ __forceinline__ void init(const GemmParams& P, bool is_a, int r0, int kbeg, int tid) {
     const float* b = is_a ? P.A : P.B;
     ld = is_a ? P.lda : P.ldb;
     const int R = is_a ? P.M : P.N;
     if constexpr (OPK == 0) {
-      p = rowptr ? rowptr + kbeg + (tid & 1) * 16 : nullptr;
+      rows[0] = row_ptr3(P, is_a, r0 + (tid >> 1));
+      p = rows[0] ? rows[0] + kbeg + (tid & 1) * 16 : nullptr;
       step = BK3;
     } else if constexpr (OPK == 1) {
       rr = r0 + (tid & 31) * 4;
@@ -540,9 +562,9 @@ struct Stream3 {
       if (rt * 16 < R) p = b + ((long)rt * (P.K >> 4) + kt) * 256 + (((tid & 15) >> 2) * 16 + 4 * (tid & 3)) * 4;
       step = 2 * 256;
     } else {
-      const int blk = tid >> 4;
-      const int kt = (kbeg >> 4) + (blk >> 3), rt = (r0 >> 4) + (blk & 7);
-      if (rt * 16 < R) p = b + ((long)kt * (R >> 4) + rt) * 256 + (((tid & 15) >> 2) * 16 + 4 * (tid & 3)) * 4;
+      const int wave = tid >> 6, lane = tid & 63;
+      const int kt = (kbeg >> 4) + (wave >> 1), rt = (r0 >> 4) + 4 * (wave & 1);
+      if ((rt + 4) * 16 <= R) p = b + ((long)kt * (R >> 4) + rt) * 256 + lane * 4;   // four row blocks in range
       step = 2L * (R >> 4) * 256;
     }
   }
@@ -551,6 +573,7 @@ struct Stream3 {
   __device__ __forceinline__ void load_full(float (&v)[4][4]) {
     const float* q = p;
     long rs = 4;                     // distance between the four 16-byte pieces
+    if constexpr (OPK == 3) rs = 256;
     if constexpr (OPK == 1) {
       rs = ld;
       if (map) {
@@ -587,9 +610,10 @@ struct Stream3 {
     }
     if (p != nullptr) p += step;
   }
-  // the mapped rows of a group straddle the batch end: take the checked path for that k-step
+  // threads that must take the checked path for this k-step even though it is a full one
   __device__ __forceinline__ bool ragged() const {
     if constexpr (OPK == 1) return map && (tile * 16 + 16 > Bwin) && (tile * 16 < Bwin);
+    if constexpr (OPK == 3) return p == nullptr;   // a row block past the edge: per-block checks
     return false;
   }
 };
@@ -601,7 +625,7 @@ template <int OPK>
 __device__ __forceinline__ void store3_chunk(char* __restrict__ hi, char* __restrict__ lo, int tid,
                                              const float (&v)[4][4], int c) {
   uint2 h, l;
-  if constexpr (OPK == 0) {          // v[s][i] = (row tid>>1, k = 16*(tid&1) + 4s + i)
+  if constexpr (OPK == 0) {          // v[c][i] = (row tid>>1, k = 16*(tid&1) + 4c + i)
     const int off = lds3_off(tid >> 1, (tid & 1) * 32 + 8 * c);
     split4(v[c][0], v[c][1], v[c][2], v[c][3], h, l);
     *reinterpret_cast<uint2*>(hi + off) = h;
@@ -613,13 +637,13 @@ __device__ __forceinline__ void store3_chunk(char* __restrict__ hi, char* __rest
     split4(v[0][c], v[1][c], v[2][c], v[3][c], h, l);
     *reinterpret_cast<uint2*>(hi + lds3_off(rowb + c, kbyte)) = h;
     *reinterpret_cast<uint2*>(lo + lds3_off(rowb + c, kbyte)) = l;
-  } else {                           // v[s][i] = (row base + s, k = kbase + i)
-    const int blk = tid >> 4;
-    const int rowb = (blk & 7) * 16 + (tid & 3) * 4;
-    const int kbyte = ((blk >> 3) * 16 + ((tid & 15) >> 2) * 4) * 2;
+  } else {                           // v[c][i] = (row 16*(4*(wave&1) + c) + lane%16, k = 16*(wave/2) + 4*(lane/16) + i)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int row = (4 * (wave & 1) + c) * 16 + (lane & 15);
+    const int kbyte = (wave >> 1) * 32 + (lane >> 4) * 8;
     split4(v[c][0], v[c][1], v[c][2], v[c][3], h, l);
-    *reinterpret_cast<uint2*>(hi + lds3_off(rowb + c, kbyte)) = h;
-    *reinterpret_cast<uint2*>(lo + lds3_off(rowb + c, kbyte)) = l;
+    *reinterpret_cast<uint2*>(hi + lds3_off(row, kbyte)) = h;
+    *reinterpret_cast<uint2*>(lo + lds3_off(row, kbyte)) = l;
   }
 }
 template <int OPK>
@@ -651,25 +675,20 @@ __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const G
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* arow = nullptr;
-  const float* brow = nullptr;
-  if constexpr (AK == A_ROW) arow = a_row_base(P, m0, tid);
-  if constexpr (BKIND == B_NK) brow = b_row_base(P, n0, tid);
-
   static_assert(NSUB3 == 1, "the pipeline below assumes one 32-deep chunk per step");
   // raw fp32 values of two tiles in flight: tile j lives in register set j & 1
   float va[2][4][4], vb[2][4][4];
   Stream3<OA> sa;
   Stream3<OB> sb;
-  sa.init(P, true, arow, m0, kbeg, tid);
-  sb.init(P, false, brow, n0, kbeg, tid);
+  sa.init(P, true, m0, kbeg, tid);
+  sb.init(P, false, n0, kbeg, tid);
   // k0 .. k0+31 entirely inside the slice: unchecked loads, except for threads on a ragged edge
   auto stage_load = [&](int k0, float (&ra)[4][4], float (&rb)[4][4]) {
     const bool full = k0 + BK3 <= kend;
     if (full && !sa.ragged()) sa.load_full(ra);
-    else load3<OA>(P, true, arow, m0, k0, kend, tid, ra);
+    else load3<OA>(P, true, sa.rows, m0, k0, kend, tid, ra);
     if (full && !sb.ragged()) sb.load_full(rb);
-    else load3<OB>(P, false, brow, n0, k0, kend, tid, rb);
+    else load3<OB>(P, false, sb.rows, n0, k0, kend, tid, rb);
     sa.advance();
     sb.advance();
   };
