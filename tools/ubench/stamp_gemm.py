@@ -15,16 +15,28 @@ hseq = torch.randn(B, T, H, device=dev)
 dw = torch.empty(4 * H, H, device=dev)
 wb = lib.vts_lstm_wgrad_workspace_bytes(B, T, H, H); ws = L.workspace(wb, dev)
 st = L.stream()
-for it in range(2):
-    raw.vts_debug_stamps(None, 1)
-    L.check(lib.vts_lstm_wgrad(L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw), 0, L.wptr(ws), wb, B, T, H, H, 1, st), "wgrad")
-    torch.cuda.synchronize()
-out = (C.c_ulonglong * 8)()
-raw.vts_debug_stamps(out, 0)
-v = list(out)
+Cin = 370
+x = torch.randn(B, T, Cin, device=dev)
+w_ih = torch.randn(4 * H, Cin, device=dev) / 16
+w_h = torch.randn(4 * H, H, device=dev) / 16
+bias = torch.zeros(4 * H, device=dev)
+dx = L.workspace(lib.vts_lstm_seqgrad_bytes(B, T, H), dev)
+stages = {
+    "wgrad_hh": lambda: lib.vts_lstm_wgrad(L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw), 0, L.wptr(ws), wb, B, T, H, H, 1, st),
+    "inproj": lambda: lib.vts_lstm_inproj_fwd(L.ptr(x), L.ptr(w_ih), L.ptr(bias), L.ptr(bias), L.wptr(gates), B, T, Cin, H, 1, st),
+    "dgrad": lambda: lib.vts_lstm_dgrad(L.wptr(gates), L.ptr(w_h), L.wptr(dx), B, T, H, H, 1, st),
+}
 names = ["issue loads", "lds reads + mfma", "barrier 1", "wait loads", "convert + store", "barrier 2"]
-nk, nwg = v[6], v[7]
-print("workgroups", nwg, "k-steps", nk)
-for n, x in zip(names, v[:6]):
-    print(f"{n:18s} {x / nk:9.1f} cycles per k-step (100 MHz memtime ticks x ?)")
-print("sum", sum(v[:6]) / nk)
+for nm, fn in stages.items():
+    for it in range(2):
+        raw.vts_debug_stamps(None, 1)
+        L.check(fn(), nm)
+        torch.cuda.synchronize()
+    out = (C.c_ulonglong * 8)()
+    raw.vts_debug_stamps(out, 0)
+    v = list(out)
+    nk, nwg = v[6], v[7]
+    print(nm, "workgroups", nwg, "k-steps per workgroup", nk / max(nwg, 1))
+    for n, x_ in zip(names, v[:6]):
+        print(f"   {n:18s} {x_ / nk:9.1f} cycles per k-step")
+    print("   sum", round(sum(v[:6]) / nk, 1))
