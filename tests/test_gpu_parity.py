@@ -141,6 +141,8 @@ def test_clamped_shape_gets_zero_gradient(golden):
     (33, 7, 37, 64, 1),      # ragged batch across three 16-row tiles, C % 2 == 1
     (40, 12, 370, 128, 2),   # LD2011 channel count (C % 4 == 2)
     (48, 9, 20, 256, 3),     # headline hidden size
+    (64, 6, 8, 256, 2),      # batch splits into 32-window pairs: the paired recurrent kernels (bf16x3)
+    (96, 5, 12, 128, 1),     # paired kernels at hidden 128, three pairs
 ])
 @pytest.mark.parametrize("mode", MODES, indirect=True)
 def test_lstm_matches_oracle(B, T, C, H, layers, mode):

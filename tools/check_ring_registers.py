@@ -4,7 +4,7 @@
 The ring buffers are filled by inline-asm global loads whose data arrives asynchronously; the
 kernel is only correct if, between a load and the hand-counted s_waitcnt that proves it landed,
 nothing reads or copies those registers.  This script compiles the source to assembly and checks
-for every lstm_rec3_* kernel that no instruction (MFMA, move, spill, another load) touches a
+for every lstm_rec3*_ kernel that no instruction (MFMA, move, spill, another load) touches a
 register written by such a load (`global_load_dwordx4 v[a:b] or a[a:b], vN, s[c:d] offset:K`) while the
 load can still be outstanding, which also re-derives every hand-counted vmcnt from the
 instruction stream.  Exit status 1 and a listing on any violation.
@@ -35,7 +35,7 @@ def regs_of(text):
 def kernels(asm):
     cur, body = None, []
     for line in asm.splitlines():
-        m = re.match(r"^(_Z\w*lstm_rec3_\w+):", line)
+        m = re.match(r"^(_Z\w*lstm_rec3p?_\w+):", line)
         if m:
             cur, body = m.group(1), []
             continue
