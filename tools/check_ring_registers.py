@@ -4,12 +4,12 @@
 The ring buffers are filled by inline-asm global loads whose data arrives asynchronously; the
 kernel is only correct if, between a load and the hand-counted s_waitcnt that proves it landed,
 nothing reads or copies those registers.  This script compiles the source to assembly and checks
-for every lstm_rec3*_ kernel that no instruction (MFMA, move, spill, another load) touches a
+for every recurrent kernel with such loads that no instruction (MFMA, move, spill, another load) touches a
 register written by such a load (`global_load_dwordx4 v[a:b] or a[a:b], vN, s[c:d] offset:K`) while the
 load can still be outstanding, which also re-derives every hand-counted vmcnt from the
 instruction stream.  Exit status 1 and a listing on any violation.
 
-    python tools/check_ring_registers.py [path/to/lstm_rec_bf16x3.hip]
+    python tools/check_ring_registers.py [kernel sources ...]
 """
 import os
 import re
@@ -35,7 +35,7 @@ def regs_of(text):
 def kernels(asm):
     cur, body = None, []
     for line in asm.splitlines():
-        m = re.match(r"^(_Z\w*lstm_rec3p?_\w+):", line)
+        m = re.match(r"^(_Z\w*lstm_rec\w*_kernel\w*):", line)
         if m:
             cur, body = m.group(1), []
             continue
@@ -71,7 +71,7 @@ def check(name, body):
     ring_re = re.compile(r"^global_load_dwordx4 ([va]\[\d+:\d+\]), v\d+, s\[\d+:\d+\]")
     is_ring = [bool(ring_re.match(l)) and i in from_asm for i, l in enumerate(code)]
     if not any(is_ring):
-        return [f"{name}: no ring loads found"]
+        return None                       # a kernel without an asm ring: nothing to check
 
     # basic blocks
     br = re.compile(r"^s_(cbranch_\w+|branch) (\S+)$")
@@ -154,18 +154,23 @@ def check(name, body):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "vae-time-series_amd", "csrc", "lstm_rec_bf16x3.hip")
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out, src],
-                       check=True, stderr=subprocess.DEVNULL)
-        asm = open(out).read()
+    csrc = os.path.join(ROOT, "vae-time-series_amd", "csrc")
+    srcs = sys.argv[1:] or [os.path.join(csrc, "lstm_rec_bf16x3.hip"), os.path.join(csrc, "lstm_rec_f32.hip")]
     problems, n = [], 0
-    for name, body in kernels(asm):
-        n += 1
-        problems += check(name, body)
+    for src in srcs:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out,
+                            src], check=True, stderr=subprocess.DEVNULL)
+            asm = open(out).read()
+        for name, body in kernels(asm):
+            res = check(name, body)
+            if res is None:
+                continue
+            n += 1
+            problems += res
     if n == 0:
-        problems.append("no lstm_rec3_* kernel found in the assembly")
+        problems.append("no kernel with an asm register ring found in the assembly")
     for p in problems:
         print(p)
     print(f"checked {n} kernels: {'FAILED' if problems else 'ok'}")

@@ -43,4 +43,58 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- W_hh register ring ---------------------------------------------------------------------------
+// The recurrent kernels consume the packed W_hh image in units of UT 16-byte fragments per lane
+// (1 KiB per fragment and wave).  A ring of four register buffers keeps three units in flight.
+// The loads are issued as inline asm and waited for with
+// hand-counted s_waitcnt: left to the compiler, the wait at the loop back-edge is vmcnt(0), which
+// drains the ring once per iteration and exposes a full L2 round trip each time.  Loads return in
+// order, so "at most N younger VMEM operations outstanding" proves a buffer has landed; operations
+// the compiler issues in between (gate loads, the previous step's stores) only make a given N
+// stricter.  The waits carry the buffer as an in/out operand so that no use can move above them,
+// and so do the loads: every definition of a ring buffer is tied to the previous one, which keeps
+// each buffer in the same physical registers around the loops.  (A fresh output register per
+// load lets the allocator pick different registers per iteration and reconcile them with moves
+// at the back-edge - moves that would copy registers whose data is still in flight.)
+// tools/check_ring_registers.py verifies on the generated ISA that nothing but these loads, the
+// LDS reads of the resident part and the MFMAs ever touches the ring registers.
+// AG selects the register file the buffer is pinned to (false: VGPRs, true: AGPRs - both are legal
+// load destinations and MFMA B operands; splitting the ring over the two files keeps the arch
+// VGPRs free for the cell update's VALU work).
+#define VTS_W_LOAD(CONS, REG, VOFF, K)                                                              \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : CONS(REG) : "v"(VOFF), "s"(sbase), "n"((K) * 1024))
+template <int UT, bool AG = false>
+__device__ __forceinline__ void w_issue(u32x4 (&w)[UT], const void* sbase, unsigned voff) {
+  static_assert(UT == 2 || UT == 4 || UT == 8, "half-unit of 2, 4 or 8 fragments");
+#pragma unroll
+  for (int i = 0; i < UT; ++i) {
+    const unsigned vo = i < 4 ? voff : voff + 4096u;
+    if constexpr (AG) VTS_W_LOAD("+a", w[i], vo, i & 3);
+    else VTS_W_LOAD("+v", w[i], vo, i & 3);
+  }
+}
+#undef VTS_W_LOAD
+template <int N, int UT, bool AG = false>
+__device__ __forceinline__ void w_wait(u32x4 (&w)[UT]) {
+  if constexpr (AG) {
+    if constexpr (UT == 8)
+      asm volatile("s_waitcnt vmcnt(%8)" : "+a"(w[0]), "+a"(w[1]), "+a"(w[2]), "+a"(w[3]), "+a"(w[4]), "+a"(w[5]),
+                   "+a"(w[6]), "+a"(w[7]) : "n"(N));
+    else if constexpr (UT == 4)
+      asm volatile("s_waitcnt vmcnt(%4)" : "+a"(w[0]), "+a"(w[1]), "+a"(w[2]), "+a"(w[3]) : "n"(N));
+    else
+      asm volatile("s_waitcnt vmcnt(%2)" : "+a"(w[0]), "+a"(w[1]) : "n"(N));
+  } else {
+    if constexpr (UT == 8)
+      asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]),
+                   "+v"(w[6]), "+v"(w[7]) : "n"(N));
+    else if constexpr (UT == 4)
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+    else
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
+  }
+}
+
 }  // namespace
