@@ -806,18 +806,10 @@ template <int AK, int BKIND, int CK>
 int launch3(const GemmParams& P, hipStream_t stream) {
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
-  if (GEMM3_LDS_BYTES > 64 * 1024) {
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<AK, BKIND, CK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
-      if (e != hipSuccess) {
-        vts_set_error("gemm_bf16x3: cannot reserve %zu B of LDS: %s", GEMM3_LDS_BYTES, hipGetErrorString(e));
-        return VTS_ERR_HIP;
-      }
-      attr_set = true;
-    }
-  }
+  static unsigned long long lds_done = 0;   // per instantiation
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_bf16x3_kernel<AK, BKIND, CK>), GEMM3_LDS_BYTES,
+                               &lds_done, "gemm_bf16x3"))
+    return rc;
   hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, BKIND, CK>), dim3((unsigned)nwg), dim3(256), GEMM3_LDS_BYTES, stream, P);
   VTS_CHECK_LAUNCH("gemm_bf16x3");
   return VTS_OK;
@@ -829,18 +821,10 @@ int launch(const GemmParams& P, hipStream_t stream) {
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
   dim3 grid((unsigned)nwg, 1, 1);
-  if (GEMM_LDS_BYTES > 64 * 1024) {
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BKIND, CK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-      if (e != hipSuccess) {
-        vts_set_error("gemm_f32: cannot reserve %zu B of LDS: %s", GEMM_LDS_BYTES, hipGetErrorString(e));
-        return VTS_ERR_HIP;
-      }
-      attr_set = true;
-    }
-  }
+  static unsigned long long lds_done = 0;   // per instantiation
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BKIND, CK>), GEMM_LDS_BYTES, &lds_done,
+                               "gemm_f32"))
+    return rc;
   hipLaunchKernelGGL((gemm_f32_kernel<AK, BKIND, CK>), grid, dim3(256), GEMM_LDS_BYTES, stream, P);
   VTS_CHECK_LAUNCH("gemm_f32");
   return VTS_OK;

@@ -480,16 +480,8 @@ int run_fwd3(float* G, float* cseq, float* hseq, float* hlast, float* clast, con
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL((pack_whh3_kernel<H, false>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3_fwd");
-  static bool attr_set = false;
-  if (!attr_set && R::LDS_F > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec3_fwd_kernel<H>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_F);
-    if (e != hipSuccess) {
-      vts_set_error("lstm_rec3_fwd: cannot reserve %zu B of LDS: %s", R::LDS_F, hipGetErrorString(e));
-      return VTS_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  static unsigned long long lds_done = 0;
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_fwd_kernel<H>), R::LDS_F, &lds_done, "lstm_rec3_fwd")) return rc;
   hipLaunchKernelGGL(lstm_rec3_fwd_kernel<H>, dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_F, stream, G, cseq, hseq,
                      hlast, clast, img, B, T);
   VTS_CHECK_LAUNCH("lstm_rec3_fwd");
@@ -504,16 +496,8 @@ int run_bwd3(float* G, const float* cseq, const float* dhseq, const float* dhlas
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL((pack_whh3_kernel<H, true>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3_bwd");
-  static bool attr_set = false;
-  if (!attr_set && R::LDS_B > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec3_bwd_kernel<H>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS_B);
-    if (e != hipSuccess) {
-      vts_set_error("lstm_rec3_bwd: cannot reserve %zu B of LDS: %s", R::LDS_B, hipGetErrorString(e));
-      return VTS_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  static unsigned long long lds_done = 0;
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_bwd_kernel<H>), R::LDS_B, &lds_done, "lstm_rec3_bwd")) return rc;
   hipLaunchKernelGGL(lstm_rec3_bwd_kernel<H>, dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_B, stream, G, cseq, dhseq,
                      dhlast, dclast, dbpart, img, B, T);
   VTS_CHECK_LAUNCH("lstm_rec3_bwd");

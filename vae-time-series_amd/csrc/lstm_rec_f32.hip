@@ -448,16 +448,9 @@ int run_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, cons
   VTS_CHECK_LAUNCH("pack_whh_fwd");
   const int nbt = (B + 15) / 16;
   const size_t lds = (2ul * 16 * H + (size_t)(C::KQ_F / 8) * C::JPW * 4 * C::NW * 64 * 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_fwd_kernel<H>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      vts_set_error("lstm_rec_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return VTS_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  static unsigned long long lds_done = 0;
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec_fwd_kernel<H>), lds, &lds_done, "lstm_rec_fwd"))
+    return rc;
   hipLaunchKernelGGL(lstm_rec_fwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), lds, stream, G, cseq, hseq, hlast, clast,
                      Wp, B, T);
   VTS_CHECK_LAUNCH("lstm_rec_fwd");
@@ -472,16 +465,9 @@ int run_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast
   VTS_CHECK_LAUNCH("pack_whh_bwd");
   const int nbt = (B + 15) / 16;
   const size_t lds = 2ul * 16 * C::LDA * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_bwd_kernel<H>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      vts_set_error("lstm_rec_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return VTS_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  static unsigned long long lds_done = 0;
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec_bwd_kernel<H>), lds, &lds_done, "lstm_rec_bwd"))
+    return rc;
   hipLaunchKernelGGL(lstm_rec_bwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), lds, stream, G, cseq, dhseq, dhlast,
                      dclast, dbpart, Wp, B, T);
   VTS_CHECK_LAUNCH("lstm_rec_bwd");

@@ -32,6 +32,24 @@ void vts_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// Kernels that use more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute, which
+// applies to the current device only: `done` (one static word per call site) remembers which
+// devices of this process have been configured.  Setting it twice is harmless, so no locking.
+static inline int vts_reserve_lds(const void* kernel, size_t bytes, unsigned long long* done, const char* what) {
+  if (bytes <= 64 * 1024) return VTS_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*done & bit) return VTS_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    vts_set_error("%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
+    return VTS_ERR_HIP;
+  }
+  *done |= bit;
+  return VTS_OK;
+}
+
 static inline bool vts_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int vts_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
