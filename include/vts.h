@@ -53,6 +53,7 @@ typedef struct ihipStream_t* vts_stream_t; /* == hipStream_t */
 #define VTS_GAUSSIAN 0
 #define VTS_GPD 1
 #define VTS_MIXTURE 2
+#define VTS_MIXTURE_SPLIT 3    /* vts_elbo_* only: the transformer variant's loss, mixture-vae-transformer.py:100-113 */
 
 const char* vts_version(void);
 const char* vts_last_error(void);
@@ -136,6 +137,15 @@ int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, f
                    size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
                    vts_stream_t stream);
 
+/* act = VTS_ACT_RELU_DROPOUT with the mask drawn by the library's counter hash instead of fed in:
+ * element (row, col) is kept iff hash(seed, row*N + col) >= drop_p * 2^32 and scaled by 1/(1-drop_p);
+ * seed 0 or drop_p 0 = eval mode (plain relu).  Backward is vts_linear_bwd with VTS_ACT_RELU_DROPOUT and
+ * keep_scale 1/(1-drop_p): it needs y only, not the mask.  Replaces dropout(relu(linear1(x))) inside
+ * nn.TransformerEncoderLayer (mixture-vae-transformer.py:39) without a [tokens, 2048] mask in memory. */
+int vts_linear_relu_dropout_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y,
+                                int64_t M, int64_t N, int64_t K, float drop_p, uint64_t seed, int dtype_mode,
+                                vts_stream_t stream);
+
 /* ---- LayerNorm over the last dim (eps 1e-5): gpd-lstm-DE.py:19,28 ; mixture-vae-DE.py:46,61 ---- */
 int vts_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                       float* mean, float* rstd, int64_t M, int64_t H, float eps, vts_stream_t stream);
@@ -164,6 +174,9 @@ int vts_reparam_bwd(int family, const float* dz, const float* logvar, const floa
  * VTS_GPD     : mse(recon,y) + beta*mean(log scale + log(1+shape*thr/scale))   gpd-lstm-DE.py:67-71
  * VTS_MIXTURE : mse + pi0*(mse over |y|<=thr + beta*KLg) + pi1*(mse + beta*KLp) mixture-vae-DE.py:115-130
  *               (NaN when no |y| <= thr, as the reference)
+ * VTS_MIXTURE_SPLIT: mse + pi0*(mse over |y|<=thr + beta*KLg) + pi1*(mse over |y|>thr + beta*KLq),
+ *               KLq = mean_B(-0.5*sum_L(1+scale-shape^2-e^scale))          mixture-vae-transformer.py:100-113
+ *               (NaN when either selection is empty, as the reference)
  * fwd writes state[16]: state[0] = loss, the rest are coefficients for bwd.  bwd scales every
  * gradient by *grad_out (device scalar, NULL = 1).  recon,y [B,fs]; latents [B,L]; pi, dpi [2]. */
 size_t vts_elbo_workspace_bytes(int64_t B, int64_t fs, int64_t L);
@@ -207,6 +220,38 @@ int vts_elbo_recon_fwd(int family, const float* recon, const float* y, const flo
 int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const float* state,
                        const float* grad_out, float threshold, float* drecon, float* dklpart,
                        int64_t nklpart, float* dpi, int64_t B, int64_t fs, vts_stream_t stream);
+
+/* ---- Transformer encoder layer pieces: nn.TransformerEncoderLayer(d_model, nhead, dropout=0.2) ----
+ * mixture-vae-transformer.py:39-40,49.  A layer is: packed in-projection (vts_linear_fwd) -> vts_mha_fwd ->
+ * out-projection -> vts_dropout_add_fwd -> vts_layernorm_fwd -> vts_linear_relu_dropout_fwd -> vts_linear_fwd
+ * -> vts_dropout_add_fwd -> vts_layernorm_fwd.
+ *
+ * Dropout sites take (keep, drop_p, seed): keep != NULL = explicit 0/1 byte mask; else seed != 0 = the
+ * library's counter hash (element idx kept iff hash(seed, idx) >= drop_p * 2^32; vts_dropout_mask writes
+ * that mask out); else no dropout (eval mode).  Kept elements are scaled by 1/(1-drop_p).
+ *
+ * vts_mha_*: softmax(q k^T / sqrt(dh)) v per (window, head), dropout on the weights.  q: Tq query rows per
+ * window (row b*Tq + i, row stride ldq floats), k and v: T rows per window (row stride ldkv); head h reads
+ * columns [h*dh, (h+1)*dh).  With the packed projection qkv[B*T, 3d]: q = qkv, k = qkv + d, v = qkv + 2d,
+ * ldq = ldkv = 3d, Tq = T.  Tq = 1 with q from a [B, d] buffer is the last-token-only form (only
+ * transformer_out[-1] is used, :50).  out [B*Tq, ldo]; lse [B, nhead, Tq] is saved for backward.  The mask
+ * (or hash index) layout is [B, nhead, Tq, T].  dh in {8, 16, 32}; strides multiples of 4 floats; the score
+ * matrix is never written to memory.  No counterpart of the attention weights is returned (need_weights=False). */
+int vts_mha_fwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out,
+                int64_t ldo, float* lse, const uint8_t* keep, float drop_p, uint64_t seed, int64_t B, int64_t T,
+                int64_t Tq, int64_t nhead, int64_t dh, vts_stream_t stream);
+int vts_mha_bwd(const float* dout, int64_t lddo, const float* q, int64_t ldq, const float* k, const float* v,
+                int64_t ldkv, const float* out, int64_t ldo, const float* lse, const uint8_t* keep,
+                float drop_p, uint64_t seed, float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv,
+                int64_t B, int64_t T, int64_t Tq, int64_t nhead, int64_t dh, vts_stream_t stream);
+/* out = residual + dropout(x) (residual NULL = 0): x + dropout1(sa) and x + dropout2(ff) of the layer */
+int vts_dropout_add_fwd(const float* residual, const float* x, const uint8_t* keep, float drop_p, uint64_t seed,
+                        float* out, int64_t n, vts_stream_t stream);
+/* dx = dout * mask / (1 - drop_p); the residual branch's gradient is dout itself */
+int vts_dropout_bwd(const float* dout, const uint8_t* keep, float drop_p, uint64_t seed, float* dx, int64_t n,
+                    vts_stream_t stream);
+/* keep[i] = 1 iff the counter hash keeps element i for (seed, drop_p) */
+int vts_dropout_mask(uint64_t seed, float drop_p, uint8_t* keep, int64_t n, vts_stream_t stream);
 
 /* ---- Adam (torch.optim.Adam defaults, no weight decay) over one flat buffer ----
  * gaussian-lstm-DE.py:142,154 ; gpd-lstm-DE.py:88,104 ; mixture-vae-DE.py:147,163.

@@ -245,15 +245,18 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------- ELBO
-// kind 0 gaussian, 1 gpd, 2 mixture.  Partial sums per block, 5 slots:
+// kind 0 gaussian, 1 gpd, 2 mixture, 3 mixture whose GPD component is scored on the rows with
+// |y| > thr and carries the Gaussian-form KL of (scale, shape) (mixture-vae-transformer.py:100-113).
+// Partial sums per block, 6 slots:
 //   0: sum (recon-y)^2          1: same over |y| <= thr      2: count |y| <= thr
-//   3: sum 1 + lv - mu^2 - e^lv 4: sum log(scale) + log(1 + shape*thr/scale)
+//   3: sum 1 + lv - mu^2 - e^lv 4: sum log(scale) + log(1 + shape*thr/scale)   (kind 3: sum 1 + sc - sh^2 - e^sc)
+//   5: sum (recon-y)^2 over |y| > thr
 __global__ __launch_bounds__(256) void elbo_partials_kernel(
     int kind, const float* __restrict__ recon, const float* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ logvar, const float* __restrict__ scale, const float* __restrict__ shape,
     float thr, long nrec, long nlat, float* __restrict__ part) {
-  __shared__ float smem[20];
-  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  __shared__ float smem[24];
+  float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const long stride = (long)gridDim.x * blockDim.x;
   const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
   for (long i = start; i < nrec; i += stride) {
@@ -261,47 +264,54 @@ __global__ __launch_bounds__(256) void elbo_partials_kernel(
     const float d = recon[i] - yv;
     const float d2 = d * d;
     s[0] += d2;
-    if (kind == 2 && fabsf(yv) <= thr) { s[1] += d2; s[2] += 1.f; }
+    if (kind >= 2) {
+      if (fabsf(yv) <= thr) { s[1] += d2; s[2] += 1.f; }
+      else s[5] += d2;
+    }
   }
   for (long i = start; i < nlat; i += stride) {
     if (kind != 1) {
       const float lv = logvar[i], mu = mean[i];
       s[3] += 1.f + lv - mu * mu - expf(lv);
     }
-    if (kind != 0) {
+    if (kind == 3) {
+      const float sc = scale[i], sh = shape[i];
+      s[4] += 1.f + sc - sh * sh - expf(sc);
+    } else if (kind != 0) {
       const float sc = scale[i], sh = shape[i];
       s[4] += logf(sc) + logf(1.f + sh * thr / sc);
     }
   }
-  block_sum<5>(s, smem);
+  block_sum<6>(s, smem);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) part[(long)blockIdx.x * 5 + i] = s[i];
+    for (int i = 0; i < 6; ++i) part[(long)blockIdx.x * 6 + i] = s[i];
   }
 }
 
 // out[0] = loss; out[1..7] = coefficients used by elbo_grads_kernel; out[8], out[9] = d loss / d pi_params
 //   1: c_all   d loss / d recon = c_all * (recon-y) (+ c_norm * (recon-y) on normal rows)
 //   2: c_norm  3: c_klg (multiplies d/dx of sum(1+lv-mu^2-e^lv))  4: c_klp
+//   5: c_ext (kind 3: extra coefficient of (recon-y) on the rows with |y| > thr)
 // klpart / nkl: optional [nkl][2] partial sums of slots 3 and 4 produced by reparam_kl_fwd_kernel.
 __global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, int nparts,
                                      const float* __restrict__ klpart, int nkl, const float* __restrict__ pi,
                                      float beta, long B, long nrec, long nlat, float* __restrict__ out) {
-  __shared__ float smem[20];
-  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  __shared__ float smem[24];
+  float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int p = threadIdx.x; p < nparts; p += blockDim.x)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) s[i] += part[(long)p * 5 + i];
+    for (int i = 0; i < 6; ++i) s[i] += part[(long)p * 6 + i];
   for (int p = threadIdx.x; p < nkl; p += blockDim.x) {
     s[3] += klpart[2 * p];
     s[4] += klpart[2 * p + 1];
   }
-  block_sum<5>(s, smem);
+  block_sum<6>(s, smem);
   if (threadIdx.x != 0) return;
   const float R = s[0] / (float)nrec;
   const float klg = -0.5f * s[3] / (float)B;
   const float klp = s[4] / (float)nlat;
-  float loss, c_all, c_norm = 0.f, c_klg = 0.f, c_klp = 0.f, dpi0 = 0.f, dpi1 = 0.f;
+  float loss, c_all, c_norm = 0.f, c_klg = 0.f, c_klp = 0.f, c_ext = 0.f, dpi0 = 0.f, dpi1 = 0.f;
   if (kind == 0) {
     loss = R + beta * klg;
     c_all = 2.f / (float)nrec;
@@ -310,6 +320,26 @@ __global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, i
     loss = R + beta * klp;
     c_all = 2.f / (float)nrec;
     c_klp = beta / (float)nlat;
+  } else if (kind == 3) {
+    const float a = pi[0], b = pi[1];
+    const float m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    const float p0 = ea / (ea + eb), p1 = eb / (ea + eb);
+    const float next = (float)nrec - s[2];
+    const float Rg = s[1] / s[2];  // 0/0 = NaN when either selection is empty, as mse_loss of an empty tensor
+    const float Rp = s[5] / next;
+    const float klq = -0.5f * s[4] / (float)B;
+    const float Ag = Rg + beta * klg;
+    const float Ap = Rp + beta * klq;
+    loss = R + p0 * Ag + p1 * Ap;
+    c_all = 2.f / (float)nrec;
+    c_norm = p0 * 2.f / s[2];
+    c_ext = p1 * 2.f / next;
+    c_klg = p0 * beta * -0.5f / (float)B;
+    c_klp = p1 * beta * -0.5f / (float)B;
+    const float sg = Ag * p0 + Ap * p1;
+    dpi0 = p0 * (Ag - sg);
+    dpi1 = p1 * (Ap - sg);
   } else {
     const float a = pi[0], b = pi[1];
     const float m = fmaxf(a, b);
@@ -329,7 +359,7 @@ __global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, i
     dpi1 = p1 * (Ap - sg);
   }
   out[0] = loss; out[1] = c_all; out[2] = c_norm; out[3] = c_klg; out[4] = c_klp;
-  out[5] = 0.f; out[6] = 0.f; out[7] = 0.f; out[8] = dpi0; out[9] = dpi1;
+  out[5] = c_ext; out[6] = 0.f; out[7] = 0.f; out[8] = dpi0; out[9] = dpi1;
 }
 
 // Elementwise ELBO gradients scaled by the upstream scalar *gout (or 1 when gout == nullptr).
@@ -343,16 +373,17 @@ __global__ void elbo_grads_kernel(int kind, const float* __restrict__ recon, con
                                   float* __restrict__ dklpart, int nkl) {
   const float go = gout ? gout[0] : 1.f;
   const float c_all = coef[1] * go, c_norm = coef[2] * go, c_klg = coef[3] * go, c_klp = coef[4] * go;
+  const float c_ext = coef[5] * go;
   const long stride = (long)gridDim.x * blockDim.x;
   const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (start == 0 && kind == 2 && dpi) { dpi[0] = coef[8] * go; dpi[1] = coef[9] * go; }
+  if (start == 0 && kind >= 2 && dpi) { dpi[0] = coef[8] * go; dpi[1] = coef[9] * go; }
   // d loss / d (KL partial sums): the same two coefficients for every block of the fused kernel
   for (long i = start; i < nkl; i += stride) { dklpart[2 * i] = c_klg; dklpart[2 * i + 1] = c_klp; }
   for (long i = start; i < nrec; i += stride) {
     const float yv = y[i];
     const float d = recon[i] - yv;
     float gr = c_all * d;
-    if (kind == 2 && fabsf(yv) <= thr) gr += c_norm * d;
+    if (kind >= 2) gr += (fabsf(yv) <= thr ? c_norm : c_ext) * d;
     drecon[i] = gr;
   }
   for (long i = start; i < nlat; i += stride) {
@@ -361,7 +392,10 @@ __global__ void elbo_grads_kernel(int kind, const float* __restrict__ recon, con
       dmean[i] = c_klg * (-2.f * mu);
       dlogvar[i] = c_klg * (1.f - expf(lv));
     }
-    if (kind != 0) {
+    if (kind == 3) {
+      dscale[i] = c_klp * (1.f - expf(scale[i]));
+      dshape[i] = c_klp * (-2.f * shape[i]);
+    } else if (kind != 0) {
       const float sc = scale[i], sh = shape[i];
       const float w = 1.f + sh * thr / sc;
       dscale[i] = c_klp * (1.f / sc - (sh * thr / (sc * sc)) / w);

@@ -53,6 +53,8 @@ struct GemmParams {
   int act;             // 0 none, 1 relu, 2 exp, 3 clamp_min(1e-6), 4 relu * keep * scale
   const float* keep;   // [M][N] 0/1 keep mask for act 4 (row stride ldc)
   float keep_scale;
+  unsigned long long drop_seed;   // act 4 without a keep mask: counter-hash dropout over index row*N + col
+  unsigned drop_thresh;           // (0 = none: plain relu)
   float* aux;          // act 3: [M][N] 1.0 where pre-activation >= 1e-6 (gradient passes)
   int accumulate;      // C += result (ksplit == 1 only)
   int ksplit;          // >1: grid.z slabs of M*N floats at C
@@ -305,6 +307,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
             } else if (P.act == 4) {
               v = fmaxf(v, 0.f);
               if (P.keep) v = v * P.keep[(long)row * ldc + col] * P.keep_scale;
+              else if (P.drop_thresh)
+                v = vts_hash32(P.drop_seed, (unsigned long long)row * P.N + col) >= P.drop_thresh ? v * P.keep_scale : 0.f;
             }
             if (P.accumulate) v += Cbase[(long)row * ldc + col];
           }
@@ -925,9 +929,11 @@ int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs,
 
 // Y[M][N] = act(X[M][K] . W[N][K]^T + bias)
 int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
-                        int N, int K, int act, const float* keep, float keep_scale, float* aux,
-                        hipStream_t stream) {
+                        int N, int K, int act, const float* keep, float keep_scale, unsigned long long drop_seed,
+                        unsigned drop_thresh, float* aux, int mode, hipStream_t stream) {
   GemmParams P{};
+  P.mode = mode;
+  P.drop_seed = drop_seed; P.drop_thresh = drop_thresh;
   P.A = X; P.B = W; P.C = Y;
   P.M = M; P.N = N; P.K = K;
   P.lda = ldx; P.ldb = K; P.ldc = ldy;
@@ -938,8 +944,9 @@ int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* b
 
 // dX[M][K] (+)= dY[M][N] . W[N][K]
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
-                       int accumulate, hipStream_t stream) {
+                       int accumulate, int mode, hipStream_t stream) {
   GemmParams P{};
+  P.mode = mode;
   P.A = dY; P.B = W; P.C = dX;
   P.M = M; P.N = K; P.K = N;
   P.lda = lddy; P.ldb = K; P.ldc = lddx;
@@ -950,8 +957,9 @@ int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, lo
 
 // dW[N][K] (+)= dY[M][N]^T . X[M][K]
 int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, float* dW, float* slabs, int ksplit,
-                       int M, int N, int K, int accumulate, hipStream_t stream) {
+                       int M, int N, int K, int accumulate, int mode, hipStream_t stream) {
   GemmParams P{};
+  P.mode = mode;
   P.A = dY; P.B = X;
   P.M = N; P.N = K; P.K = M;
   P.lda = lddy; P.ldb = ldx; P.ldc = K;

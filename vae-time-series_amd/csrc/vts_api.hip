@@ -15,11 +15,19 @@ int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int
 int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
                        int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream);
 int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
-                        int N, int K, int act, const float* keep, float keep_scale, float* aux, hipStream_t stream);
+                        int N, int K, int act, const float* keep, float keep_scale, unsigned long long drop_seed,
+                        unsigned drop_thresh, float* aux, int mode, hipStream_t stream);
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
-                       int accumulate, hipStream_t stream);
+                       int accumulate, int mode, hipStream_t stream);
 int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, float* dW, float* slabs, int ksplit,
-                       int M, int N, int K, int accumulate, hipStream_t stream);
+                       int M, int N, int K, int accumulate, int mode, hipStream_t stream);
+int vts_attn_mha(int bwd, const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, long ldo,
+                 float* lse, const unsigned char* keep, float drop_p, unsigned long long seed, const float* dout,
+                 long lddo, float* dq, long lddq, float* dk, float* dv, long lddkv, int B, int T, int Tq, int nhead,
+                 int dh, hipStream_t st);
+int vts_attn_dropout_add(const float* residual, const float* x, const unsigned char* keep, float drop_p,
+                         unsigned long long seed, float* out, long n, hipStream_t st);
+int vts_attn_dropout_mask(unsigned long long seed, float drop_p, unsigned char* keep, long n, hipStream_t st);
 bool vts_lstm_hidden_supported(int H);
 bool vts_lstm_rec3_supported(int H);
 int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
@@ -103,9 +111,15 @@ static inline long pad16(long b) { return (b + 15) / 16 * 16; }
 
 static bool fits_int(int64_t v) { return v >= 0 && v < (int64_t)2147483647; }
 
+// Arithmetic of a Linear product: the split-bf16 kernels pay off once the product is large enough to
+// fill the chip; the small heads and decoder layers stay on the f32 matrix cores.
+static int linear_mode(int dtype_mode, int64_t M, int64_t N, int64_t K) {
+  return (dtype_mode == 1 && M * N * K >= ((int64_t)1 << 26)) ? 1 : 0;
+}
+
 extern "C" {
 
-const char* vts_version(void) { return "vts-hip 0.2 (gfx950, fp32 + bf16x3 mfma)"; }
+const char* vts_version(void) { return "vts-hip 0.3 (gfx950, fp32 + bf16x3 mfma, lstm + transformer encoders)"; }
 const char* vts_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------ LSTM
@@ -274,8 +288,21 @@ int vts_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bia
   VTS_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0 && ldx >= K, "linear_fwd: bad arguments");
   VTS_REQUIRE(act >= 0 && act <= 4, "linear_fwd: unknown activation %d", act);
   VTS_REQUIRE(fits_int(M) && fits_int(N) && fits_int(K), "linear_fwd: dimension too large");
-  return vts_gemm_linear_fwd(x, ldx, w, bias, y, N, (int)M, (int)N, (int)K, act, keep, keep_scale, aux,
-                             reinterpret_cast<hipStream_t>(stream));
+  return vts_gemm_linear_fwd(x, ldx, w, bias, y, N, (int)M, (int)N, (int)K, act, keep, keep_scale, 0ull, 0u, aux,
+                             linear_mode(dtype_mode, M, N, K), reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_linear_relu_dropout_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t M,
+                                int64_t N, int64_t K, float drop_p, uint64_t seed, int dtype_mode,
+                                vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0 && ldx >= K, "linear_relu_dropout_fwd: bad arguments");
+  VTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_relu_dropout_fwd: drop_p %g outside [0, 1)", (double)drop_p);
+  VTS_REQUIRE(fits_int(M) && fits_int(N) && fits_int(K), "linear_relu_dropout_fwd: dimension too large");
+  const bool on = drop_p > 0.f && seed != 0;
+  return vts_gemm_linear_fwd(x, ldx, w, bias, y, N, (int)M, (int)N, (int)K, VTS_ACT_RELU_DROPOUT, nullptr,
+                             on ? 1.f / (1.f - drop_p) : 1.f, seed, on ? vts_drop_thresh(drop_p) : 0u, nullptr,
+                             linear_mode(dtype_mode, M, N, K), reinterpret_cast<hipStream_t>(stream));
 }
 
 struct LinWs {
@@ -317,9 +344,11 @@ int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, f
     VTS_RC(vts_ew_act_bwd(act, dy, y, aux, keep_scale, ws.dpre, M * N, st));
     dpre = ws.dpre;
   }
-  if (dx) VTS_RC(vts_gemm_linear_dx(dpre, N, w, dx, lddx, (int)M, (int)N, (int)K, dx_accumulate, st));
+  const int mode = linear_mode(dtype_mode, M, N, K);
+  if (dx) VTS_RC(vts_gemm_linear_dx(dpre, N, w, dx, lddx, (int)M, (int)N, (int)K, dx_accumulate, mode, st));
   if (dw)
-    VTS_RC(vts_gemm_linear_dw(dpre, N, x, ldx, dw, ws.slabs, ws.ksplit, (int)M, (int)N, (int)K, param_accumulate, st));
+    VTS_RC(vts_gemm_linear_dw(dpre, N, x, ldx, dw, ws.slabs, ws.ksplit, (int)M, (int)N, (int)K, param_accumulate,
+                              mode, st));
   if (db) {
     VTS_RC(vts_ew_colsum_rows(dpre, N, (int)M, (int)N, ws.colpart, st));
     VTS_RC(vts_colsum_partials(ws.colpart, db, vts_ew_colsum_chunks((int)M), (int)N, N, param_accumulate, st));
@@ -379,17 +408,17 @@ int vts_reparam_bwd(int family, const float* dz, const float* logvar, const floa
 }
 
 size_t vts_elbo_workspace_bytes(int64_t B, int64_t fs, int64_t L) {
-  return round256((size_t)vts_ew_elbo_blocks(B * fs, B * L) * 5 * sizeof(float));
+  return round256((size_t)vts_ew_elbo_blocks(B * fs, B * L) * 6 * sizeof(float));
 }
 
 int vts_elbo_fwd(int family, const float* recon, const float* y, const float* mean, const float* logvar,
                  const float* scale, const float* shape, const float* pi, float threshold, float beta, float* state,
                  void* workspace, size_t workspace_bytes, int64_t B, int64_t fs, int64_t L, vts_stream_t stream) {
-  VTS_REQUIRE(family >= 0 && family <= 2 && recon && y && state && workspace && B > 0 && fs > 0 && L > 0,
+  VTS_REQUIRE(family >= 0 && family <= 3 && recon && y && state && workspace && B > 0 && fs > 0 && L > 0,
               "elbo_fwd: bad arguments");
   VTS_REQUIRE(family == VTS_GPD || (mean && logvar), "elbo_fwd: gaussian inputs missing");
   VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape), "elbo_fwd: gpd inputs missing");
-  VTS_REQUIRE(family != VTS_MIXTURE || pi, "elbo_fwd: mixture needs pi");
+  VTS_REQUIRE(family < VTS_MIXTURE || pi, "elbo_fwd: mixture needs pi");
   VTS_REQUIRE(workspace_bytes >= vts_elbo_workspace_bytes(B, fs, L), "elbo_fwd: workspace too small");
   return vts_ew_elbo_fwd(family, recon, y, mean, logvar, scale, shape, pi, threshold, beta, B, (int)fs, (int)L,
                          reinterpret_cast<float*>(workspace), state, reinterpret_cast<hipStream_t>(stream));
@@ -399,7 +428,7 @@ int vts_elbo_bwd(int family, const float* recon, const float* y, const float* me
                  const float* scale, const float* shape, const float* state, const float* grad_out, float threshold,
                  float* drecon, float* dmean, float* dlogvar, float* dscale, float* dshape, float* dpi, int64_t B,
                  int64_t fs, int64_t L, vts_stream_t stream) {
-  VTS_REQUIRE(family >= 0 && family <= 2 && recon && y && state && drecon && B > 0 && fs > 0 && L > 0,
+  VTS_REQUIRE(family >= 0 && family <= 3 && recon && y && state && drecon && B > 0 && fs > 0 && L > 0,
               "elbo_bwd: bad arguments");
   VTS_REQUIRE(family == VTS_GPD || (mean && logvar && dmean && dlogvar), "elbo_bwd: gaussian buffers missing");
   VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape && dscale && dshape), "elbo_bwd: gpd buffers missing");
@@ -459,6 +488,62 @@ int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const flo
               "elbo_recon_bwd: bad arguments");
   return vts_ew_elbo_recon_bwd(family, recon, y, state, grad_out, threshold, B, (int)fs, drecon, dklpart,
                                (int)nklpart, dpi, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------- transformer encoder pieces
+static int mha_check(const char* what, int64_t B, int64_t T, int64_t Tq, int64_t nhead, int64_t dh, int64_t ldq,
+                     int64_t ldkv, int64_t ldo, float drop_p) {
+  VTS_REQUIRE(B > 0 && T > 0 && Tq > 0 && nhead > 0 && dh > 0, "%s: bad dimensions", what);
+  VTS_REQUIRE(fits_int(B * nhead) && fits_int(T) && fits_int(Tq), "%s: dimension too large", what);
+  VTS_REQUIRE(ldq >= nhead * dh && ldkv >= nhead * dh && ldo >= nhead * dh, "%s: row stride below nhead*dh", what);
+  VTS_REQUIRE((ldq % 4) == 0 && (ldkv % 4) == 0 && (ldo % 4) == 0, "%s: row strides must be multiples of 4 floats", what);
+  VTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "%s: drop_p %g outside [0, 1)", what, (double)drop_p);
+  return VTS_OK;
+}
+
+int vts_mha_fwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int64_t ldo,
+                float* lse, const uint8_t* keep, float drop_p, uint64_t seed, int64_t B, int64_t T, int64_t Tq,
+                int64_t nhead, int64_t dh, vts_stream_t stream) {
+  VTS_REQUIRE(q && k && v && out && lse, "mha_fwd: null pointer");
+  VTS_RC(mha_check("mha_fwd", B, T, Tq, nhead, dh, ldq, ldkv, ldo, drop_p));
+  VTS_REQUIRE(vts_aligned16(q) && vts_aligned16(k) && vts_aligned16(v) && vts_aligned16(out),
+              "mha_fwd: q, k, v, out must be 16-byte aligned");
+  return vts_attn_mha(0, q, ldq, k, v, ldkv, out, ldo, lse, keep, drop_p, seed, nullptr, 0, nullptr, 0, nullptr,
+                      nullptr, 0, (int)B, (int)T, (int)Tq, (int)nhead, (int)dh, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_mha_bwd(const float* dout, int64_t lddo, const float* q, int64_t ldq, const float* k, const float* v,
+                int64_t ldkv, const float* out, int64_t ldo, const float* lse, const uint8_t* keep, float drop_p,
+                uint64_t seed, float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv, int64_t B, int64_t T,
+                int64_t Tq, int64_t nhead, int64_t dh, vts_stream_t stream) {
+  VTS_REQUIRE(dout && q && k && v && out && lse && dq && dk && dv, "mha_bwd: null pointer");
+  VTS_RC(mha_check("mha_bwd", B, T, Tq, nhead, dh, ldq, ldkv, ldo, drop_p));
+  VTS_REQUIRE(lddo >= nhead * dh && lddq >= nhead * dh && lddkv >= nhead * dh && (lddo % 4) == 0 && (lddq % 4) == 0 &&
+                  (lddkv % 4) == 0,
+              "mha_bwd: gradient row strides must be multiples of 4 floats and at least nhead*dh");
+  VTS_REQUIRE(vts_aligned16(dout) && vts_aligned16(q) && vts_aligned16(k) && vts_aligned16(v) && vts_aligned16(out) &&
+                  vts_aligned16(dq) && vts_aligned16(dk) && vts_aligned16(dv),
+              "mha_bwd: tensors must be 16-byte aligned");
+  return vts_attn_mha(1, q, ldq, k, v, ldkv, const_cast<float*>(out), ldo, const_cast<float*>(lse), keep, drop_p, seed,
+                      dout, lddo, dq, lddq, dk, dv, lddkv, (int)B, (int)T, (int)Tq, (int)nhead, (int)dh,
+                      reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_dropout_add_fwd(const float* residual, const float* x, const uint8_t* keep, float drop_p, uint64_t seed,
+                        float* out, int64_t n, vts_stream_t stream) {
+  VTS_REQUIRE(x && out && n > 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_add_fwd: bad arguments");
+  return vts_attn_dropout_add(residual, x, keep, drop_p, seed, out, n, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_dropout_bwd(const float* dout, const uint8_t* keep, float drop_p, uint64_t seed, float* dx, int64_t n,
+                    vts_stream_t stream) {
+  VTS_REQUIRE(dout && dx && n > 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_bwd: bad arguments");
+  return vts_attn_dropout_add(nullptr, dout, keep, drop_p, seed, dx, n, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_dropout_mask(uint64_t seed, float drop_p, uint8_t* keep, int64_t n, vts_stream_t stream) {
+  VTS_REQUIRE(keep && n > 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_mask: bad arguments");
+  return vts_attn_dropout_mask(seed, drop_p, keep, n, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------ Adam

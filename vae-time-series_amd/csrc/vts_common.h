@@ -94,3 +94,47 @@ static __device__ __forceinline__ void split4(float x0, float x1, float x2, floa
   split2(x2, x3, hi.y, lo.y);
 }
 
+// ---- counter-based dropout ----------------------------------------------------------------------
+// Element `idx` of a tensor whose mask was drawn with `seed` is kept iff vts_hash32(seed, idx) >=
+// thresh, thresh = p * 2^32.  A pure function of (seed, idx): the backward pass and any number of
+// kernels regenerate the same mask without storing it.  One round of a multiply/xor-shift mixer
+// over the low index word, with the high word and the second seed word folded in.
+__host__ __device__ static inline unsigned vts_hash32(unsigned long long seed, unsigned long long idx) {
+  unsigned x = (unsigned)idx ^ (unsigned)seed;
+  x += (unsigned)(idx >> 32) * 0x9E3779B9u + (unsigned)(seed >> 32);
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+static inline unsigned vts_drop_thresh(float p) {
+  if (!(p > 0.f)) return 0u;
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+}
+
+// How a dropout site gets its mask: explicit bytes (tests, replay of recorded draws), the counter
+// hash (training), or nothing (eval / p == 0).  mult(idx) is the factor applied to element idx.
+struct VtsDrop {
+  const unsigned char* keep;   // [n] 0/1 or null
+  unsigned long long seed;
+  unsigned thresh;             // 0 = no hashed dropout
+  float scale;                 // 1 / (1 - p)
+  __device__ __forceinline__ float mult(unsigned long long idx) const {
+    if (keep) return keep[idx] ? scale : 0.f;
+    if (thresh) return vts_hash32(seed, idx) >= thresh ? scale : 0.f;
+    return 1.f;
+  }
+};
+static inline VtsDrop vts_make_drop(const unsigned char* keep, float p, unsigned long long seed) {
+  VtsDrop d{};
+  if (p > 0.f && (keep || seed)) {
+    d.keep = keep;
+    d.seed = seed;
+    d.thresh = keep ? 0u : vts_drop_thresh(p);
+    d.scale = 1.f / (1.f - p);
+  } else {
+    d.scale = 1.f;
+  }
+  return d;
+}

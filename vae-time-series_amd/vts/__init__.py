@@ -1,4 +1,4 @@
-"""vts: the LSTM-VAE train step of letrucnhi160703/vae-time-series on MI355X (gfx950).
+"""vts: the VAE train step (LSTM and transformer encoders) of letrucnhi160703/vae-time-series on MI355X (gfx950).
 
 Python face of libvts_hip.so: drop-in modules and functions for the reference's torch call
 sites.  All arithmetic runs in the HIP library; torch supplies device memory, streams and
@@ -7,14 +7,17 @@ torch.distributed.  Importing works without a GPU; calling any op without one ra
 from . import _lib
 from .functional import get_mode, set_mode
 from .functional import (gaussian_elbo, gpd_elbo, layer_norm, linear, lstm, mixture_elbo,
-                         reparameterize_gaussian, reparameterize_gpd, reparameterize_mixture)
-from .modules import (GPDVAE, LSTM, GaussianVAE, LayerNorm, Linear, MixtureVAE, build_model)
+                         reparameterize_gaussian, reparameterize_gpd, reparameterize_mixture,
+                         mixture_split_elbo, multi_head_attention, dropout_add, dropout_mask)
+from .modules import (GPDVAE, LSTM, GaussianVAE, LayerNorm, Linear, MixtureVAE, build_model,
+                      TransformerEncoderLayer, TransformerMixtureVAE)
 from .train import Adam, FlatParameters, train_step
 from .parallel import DataParallelTrainer, shard_batch
 
 __all__ = [
     "LSTM", "Linear", "LayerNorm", "GaussianVAE", "GPDVAE", "MixtureVAE", "build_model",
     "lstm", "linear", "layer_norm", "reparameterize_gaussian", "reparameterize_gpd",
-    "reparameterize_mixture", "gaussian_elbo", "gpd_elbo", "mixture_elbo",
+    "reparameterize_mixture", "gaussian_elbo", "gpd_elbo", "mixture_elbo", "mixture_split_elbo",
+    "multi_head_attention", "dropout_add", "dropout_mask", "TransformerEncoderLayer", "TransformerMixtureVAE",
     "set_mode", "get_mode", "Adam", "FlatParameters", "train_step", "DataParallelTrainer", "shard_batch",
 ]

@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvts_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_EXP, ACT_CLAMP_MIN, ACT_RELU_DROPOUT = 0, 1, 2, 3, 4
-GAUSSIAN, GPD, MIXTURE = 0, 1, 2
+GAUSSIAN, GPD, MIXTURE, MIXTURE_SPLIT = 0, 1, 2, 3
 FAMILY = {"gaussian": GAUSSIAN, "gpd": GPD, "mixture": MIXTURE}
 
-_i64, _f32, _int, _ptr, _sz = C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_size_t
+_i64, _f32, _int, _ptr, _sz, _u64 = C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes); mirrors include/vts.h one to one
 SIGNATURES = {
@@ -58,6 +58,14 @@ SIGNATURES = {
     "vts_elbo_recon_fwd": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64,
                                   _ptr]),
     "vts_elbo_recon_bwd": (_int, [_int, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr]),
+    "vts_linear_relu_dropout_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _u64, _int, _ptr]),
+    "vts_mha_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _u64, _i64, _i64, _i64, _i64,
+                           _i64, _ptr]),
+    "vts_mha_bwd": (_int, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _u64, _ptr, _i64,
+                           _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr]),
+    "vts_dropout_add_fwd": (_int, [_ptr, _ptr, _ptr, _f32, _u64, _ptr, _i64, _ptr]),
+    "vts_dropout_bwd": (_int, [_ptr, _ptr, _f32, _u64, _ptr, _i64, _ptr]),
+    "vts_dropout_mask": (_int, [_u64, _f32, _ptr, _i64, _ptr]),
     "vts_adam_step": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr]),
     "vts_scale": (_int, [_ptr, _ptr, _ptr, _i64, _ptr]),
 }
@@ -99,6 +107,15 @@ def ptr(t: Optional[torch.Tensor]):
         raise RuntimeError("vts kernels run on a ROCm device only: got a tensor on " + str(t.device))
     if t.dtype != torch.float32:
         raise RuntimeError(f"vts kernels take float32 tensors, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def bptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a uint8 mask (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
+        raise RuntimeError("vts byte masks must be contiguous uint8 tensors on a ROCm device")
     return C.c_void_p(t.data_ptr())
 
 

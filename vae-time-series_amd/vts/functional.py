@@ -148,7 +148,7 @@ def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int
 # ----------------------------------------------------------------------------------- Linear
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act: int, keep):
+    def forward(ctx, x, weight, bias, act: int, keep, drop_p: float = DROP_P, seed: int = 0):
         _need_gpu(x)
         lib = L.load()
         if x.dim() != 2 or x.stride(1) != 1:
@@ -158,12 +158,19 @@ class _Linear(torch.autograd.Function):
         weight = weight.contiguous()
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         aux = torch.empty(M, N, device=x.device, dtype=torch.float32) if act == L.ACT_CLAMP_MIN else None
-        if act == L.ACT_RELU_DROPOUT and keep is None:
+        if act == L.ACT_RELU_DROPOUT and keep is None and not seed:
             act = L.ACT_RELU  # eval mode
         keep = _c(keep)
-        scale = 1.0 / (1.0 - DROP_P)
-        L.check(lib.vts_linear_fwd(L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(_c(bias)), L.ptr(y), M, N, K, act,
-                                   L.ptr(keep), scale, L.ptr(aux), _MODE, L.stream()), "vts_linear_fwd")
+        scale = 1.0 / (1.0 - drop_p)
+        if act == L.ACT_RELU_DROPOUT and keep is None:
+            # mask from the library's counter hash: nothing but y is needed for backward
+            L.check(L.timer.call("linear_relu_dropout_fwd", lib.vts_linear_relu_dropout_fwd, L.ptr(x), x.stride(0),
+                                 L.ptr(weight), L.ptr(_c(bias)), L.ptr(y), M, N, K, drop_p, seed, _MODE, L.stream()),
+                    "vts_linear_relu_dropout_fwd")
+        else:
+            L.check(L.timer.call("linear_fwd", lib.vts_linear_fwd, L.ptr(x), x.stride(0), L.ptr(weight),
+                                 L.ptr(_c(bias)), L.ptr(y), M, N, K, act, L.ptr(keep), scale, L.ptr(aux), _MODE,
+                                 L.stream()), "vts_linear_fwd")
         ctx.act = act
         ctx.scale = scale
         ctx.has_bias = bias is not None
@@ -182,15 +189,18 @@ class _Linear(torch.autograd.Function):
         db = torch.empty(N, device=x.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.vts_linear_bwd_workspace_bytes(M, N, K)
         ws = L.workspace(ws_bytes, x.device)
-        L.check(lib.vts_linear_bwd(L.ptr(dy), L.ptr(y), L.ptr(aux), ctx.act, ctx.scale, L.ptr(x), x.stride(0),
-                                   L.ptr(weight), L.ptr(dx), K, 0, L.ptr(dw), L.ptr(db), 0, L.wptr(ws), ws_bytes,
-                                   M, N, K, _MODE, L.stream()), "vts_linear_bwd")
-        return dx, dw, db, None, None
+        L.check(L.timer.call("linear_bwd", lib.vts_linear_bwd, L.ptr(dy), L.ptr(y), L.ptr(aux), ctx.act, ctx.scale,
+                             L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(dx), K, 0, L.ptr(dw), L.ptr(db), 0,
+                             L.wptr(ws), ws_bytes, M, N, K, _MODE, L.stream()), "vts_linear_bwd")
+        return dx, dw, db, None, None, None, None
 
 
-def linear(x, weight, bias=None, act: int = L.ACT_NONE, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x @ weight.T + bias) with the activation (and dropout mask) fused into the GEMM epilogue."""
-    return _Linear.apply(x, weight, bias, act, keep)
+def linear(x, weight, bias=None, act: int = L.ACT_NONE, keep: Optional[torch.Tensor] = None,
+           drop_p: float = DROP_P, seed: int = 0) -> torch.Tensor:
+    """act(x @ weight.T + bias) with the activation (and dropout) fused into the GEMM epilogue.
+    ACT_RELU_DROPOUT takes its mask from ``keep`` (float 0/1, [M, N]) or, when ``keep`` is None and
+    ``seed`` is non-zero, from the library's counter hash; neither = eval mode."""
+    return _Linear.apply(x, weight, bias, act, keep, drop_p, seed)
 
 
 # -------------------------------------------------------------------------------- LayerNorm
@@ -408,7 +418,7 @@ class _Elbo(torch.autograd.Function):
             dmean, dlogvar = new(), new()
         if fam != L.GAUSSIAN:
             dscale, dshape = new(), new()
-        if fam == L.MIXTURE:
+        if fam >= L.MIXTURE:
             dpi = torch.empty(2, device=dev, dtype=torch.float32)
         L.check(L.timer.call("elbo_bwd", lib.vts_elbo_bwd, fam, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape),
                                  L.ptr(state), L.ptr(gout), ctx.threshold, L.ptr(drecon), L.ptr(dmean),
@@ -477,3 +487,125 @@ def mixture_elbo(recon, y, mean, logvar, scale, shape, pi_params, threshold: flo
     if kl is not None and kl.matches((mean, logvar, scale, shape), threshold):
         return _ElboRecon.apply(L.MIXTURE, recon, y, kl.klpart, pi_params, float(threshold), beta, mean.shape[1])
     return _Elbo.apply(L.MIXTURE, recon, y, mean, logvar, scale, shape, pi_params, float(threshold), beta)
+
+
+def mixture_split_elbo(recon, y, mean, logvar, scale, shape, pi_params, threshold: float,
+                       beta: float = 1.0) -> torch.Tensor:
+    """Loss of the transformer variant (mixture-vae-transformer.py:100-113):
+    mse + pi_g * (mse over |y| <= threshold + beta * KL_gaussian(mean, logvar))
+        + pi_p * (mse over |y| > threshold + beta * KL_gaussian-form(shape, scale)).
+    NaN when either selection is empty, as in the reference."""
+    return _Elbo.apply(L.MIXTURE_SPLIT, recon, y, mean, logvar, scale, shape, pi_params, float(threshold), beta)
+
+
+# ---------------------------------------------------------------- transformer encoder pieces
+def new_seed() -> int:
+    """A non-zero seed for one dropout site, drawn from torch's CPU generator (so torch.manual_seed
+    makes a training run repeatable).  The draw is a host-side op: no device synchronisation."""
+    return int(torch.randint(1, 2 ** 62, (1,)).item())
+
+
+def _byte_mask(keep: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if keep is None:
+        return None
+    return keep.to(torch.uint8).contiguous()
+
+
+class _MHA(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh)) v over the heads of one encoder layer, dropout on the weights.
+    Packed form  : q is None, kv = qkv [B, T, 3d] (the in-projection's output)  -> out [B, T, d].
+    Last-token   : q [B, d] (one query per window), kv [B, T, 2d]               -> out [B, d]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, nhead: int, keep, drop_p: float, seed: int):
+        _need_gpu(kv)
+        lib = L.load()
+        kv = kv.contiguous()
+        B, T, W = kv.shape
+        packed = q is None
+        d = W // 3 if packed else W // 2
+        dh = d // nhead
+        if packed:
+            Tq, qbuf, ldq, koff = T, kv, W, d
+        else:
+            q = q.contiguous()
+            Tq, qbuf, ldq, koff = 1, q, d, 0
+        out = torch.empty(B * Tq, d, device=kv.device, dtype=torch.float32)
+        lse = torch.empty(B * nhead * Tq, device=kv.device, dtype=torch.float32)
+        keep = _byte_mask(keep)
+        flat = kv.view(-1)
+        L.check(L.timer.call("mha_fwd", lib.vts_mha_fwd, L.ptr(qbuf), ldq, L.ptr(flat[koff:]), L.ptr(flat[koff + d:]),
+                             W, L.ptr(out), d, L.ptr(lse), L.bptr(keep), drop_p, seed, B, T, Tq, nhead, dh,
+                             L.stream()), "vts_mha_fwd")
+        ctx.cfg = (B, T, Tq, W, d, nhead, dh, packed, drop_p, seed)
+        ctx.save_for_backward(q, kv, out, lse, keep)
+        return out.view(B, T, d) if packed else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        q, kv, out, lse, keep = ctx.saved_tensors
+        B, T, Tq, W, d, nhead, dh, packed, drop_p, seed = ctx.cfg
+        dout = dout.contiguous()
+        dkv = torch.empty_like(kv)
+        dflat, flat = dkv.view(-1), kv.view(-1)
+        if packed:
+            qbuf, ldq, koff, dq, dqbuf = kv, W, d, None, dkv
+        else:
+            dq = torch.empty_like(q)
+            qbuf, ldq, koff, dqbuf = q, d, 0, dq
+        L.check(L.timer.call("mha_bwd", lib.vts_mha_bwd, L.ptr(dout), d, L.ptr(qbuf), ldq, L.ptr(flat[koff:]),
+                             L.ptr(flat[koff + d:]), W, L.ptr(out), d, L.ptr(lse), L.bptr(keep), drop_p, seed,
+                             L.ptr(dqbuf), ldq, L.ptr(dflat[koff:]), L.ptr(dflat[koff + d:]), W, B, T, Tq, nhead, dh,
+                             L.stream()), "vts_mha_bwd")
+        return dq, dkv, None, None, None, None
+
+
+def multi_head_attention(kv, nhead: int, q=None, keep=None, drop_p: float = 0.0, seed: int = 0):
+    """Self-attention core of nn.MultiheadAttention between the in- and out-projections.
+    ``kv``: packed projections [B, T, 3d] (q, k, v side by side), or [B, T, 2d] with ``q`` [B, d] for
+    the one-query-per-window form.  ``keep``: 0/1 mask [B, nhead, Tq, T]; else ``seed`` != 0 draws the
+    mask with the library's counter hash; else no dropout."""
+    return _MHA.apply(q, kv, nhead, keep, drop_p, seed)
+
+
+class _DropoutAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, residual, x, keep, drop_p: float, seed: int):
+        _need_gpu(x)
+        lib = L.load()
+        x = x.contiguous()
+        residual = residual.contiguous()
+        keep = _byte_mask(keep)
+        out = torch.empty_like(x)
+        L.check(L.timer.call("dropout_add_fwd", lib.vts_dropout_add_fwd, L.ptr(residual), L.ptr(x), L.bptr(keep),
+                             drop_p, seed, L.ptr(out), x.numel(), L.stream()), "vts_dropout_add_fwd")
+        ctx.cfg = (drop_p, seed)
+        ctx.save_for_backward(keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        (keep,) = ctx.saved_tensors
+        drop_p, seed = ctx.cfg
+        dout = dout.contiguous()
+        if keep is None and not seed:
+            return dout, dout, None, None, None
+        dx = torch.empty_like(dout)
+        L.check(L.timer.call("dropout_bwd", lib.vts_dropout_bwd, L.ptr(dout), L.bptr(keep), drop_p, seed, L.ptr(dx),
+                             dout.numel(), L.stream()), "vts_dropout_bwd")
+        return dout, dx, None, None, None
+
+
+def dropout_add(residual, x, keep=None, drop_p: float = 0.0, seed: int = 0):
+    """residual + dropout(x): the two residual sites of a post-norm encoder layer."""
+    return _DropoutAdd.apply(residual, x, keep, drop_p, seed)
+
+
+def dropout_mask(seed: int, drop_p: float, shape, device) -> torch.Tensor:
+    """The uint8 keep mask the counter hash yields for (seed, drop_p) over a tensor of ``shape``."""
+    lib = L.load()
+    keep = torch.empty(shape, dtype=torch.uint8, device=device)
+    L.check(lib.vts_dropout_mask(seed, drop_p, L.bptr(keep), keep.numel(), L.stream()), "vts_dropout_mask")
+    return keep

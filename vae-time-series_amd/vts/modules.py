@@ -237,6 +237,162 @@ class MixtureVAE(nn.Module):
         return F.mixture_elbo(reconstructed, y, mean, logvar, scale, shape, self.pi_params, thr, self.beta, kl=kl)
 
 
+# ------------------------------------------------------------------- transformer mixture VAE
+TRANSFORMER_DROP_P = 0.2   # nn.TransformerEncoderLayer(dropout=0.2), Decoder nn.Dropout(0.2)
+
+
+class _Site:
+    """One dropout site of one forward pass: its mask is fed in (parity), drawn by the library's
+    counter hash from a fresh seed (training), or absent (eval)."""
+
+    def __init__(self, noise: Noise, key: str, training: bool):
+        self.keep = noise.get(key) if noise is not None else None
+        self.seed = F.new_seed() if (self.keep is None and training and noise is None) else 0
+
+
+class SelfAttention(nn.Module):
+    """Parameter holder shaped like nn.MultiheadAttention (in_proj_weight [3d,d], in_proj_bias [3d],
+    out_proj.{weight,bias}) with torch's initialisation (xavier-uniform in-projection, zero biases)."""
+
+    def __init__(self, d_model: int, nhead: int):
+        super().__init__()
+        if d_model % nhead or (d_model // nhead) not in (8, 16, 32):
+            raise NotImplementedError("vts attention: head width d_model/nhead must be 8, 16 or 32")
+        self.embed_dim, self.num_heads = d_model, nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward=2048, dropout=0.2) as the reference
+    builds it (mixture-vae-transformer.py:39): post-norm, ReLU, four dropout sites.  Works on
+    batch-major [B, T, d] (the reference permutes to seq-first at :49; attention is per window either way).
+
+    ``last_only``: produce the layer's output for the final position only ([B, d]).  The reference reads
+    nothing but transformer_out[-1] (:50), so the last layer of the stack needs keys and values for every
+    position but a query, residual, norms and feed-forward for one: 1/T of the layer's work."""
+
+    def __init__(self, d_model: int, nhead: int, dim_feedforward: int = 2048, dropout: float = TRANSFORMER_DROP_P):
+        super().__init__()
+        self.self_attn = SelfAttention(d_model, nhead)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
+        self.p = dropout
+
+    def forward(self, x: torch.Tensor, index: int, noise: Noise = None, last_only: bool = False) -> torch.Tensor:
+        B, T, d = x.shape
+        sa, p = self.self_attn, self.p
+        sites = {k: _Site(noise, f"l{index}.{k}_keep", self.training) for k in ("attn", "drop1", "ff", "drop2")}
+        x2 = x.reshape(B * T, d)
+        if last_only:
+            pick = lambda m: None if m is None else m[:, -1]
+            res = x[:, -1, :]
+            q = F.linear(res, sa.in_proj_weight[:d], sa.in_proj_bias[:d])
+            kv = F.linear(x2, sa.in_proj_weight[d:], sa.in_proj_bias[d:]).view(B, T, 2 * d)
+            akeep = sites["attn"].keep
+            att = F.multi_head_attention(kv, sa.num_heads, q=q, keep=None if akeep is None else akeep[:, :, -1:, :],
+                                         drop_p=p, seed=sites["attn"].seed)
+        else:
+            pick = lambda m: m
+            res = x2
+            qkv = F.linear(x2, sa.in_proj_weight, sa.in_proj_bias).view(B, T, 3 * d)
+            att = F.multi_head_attention(qkv, sa.num_heads, keep=sites["attn"].keep, drop_p=p,
+                                         seed=sites["attn"].seed).view(B * T, d)
+        h = F.dropout_add(res, sa.out_proj(att), pick(sites["drop1"].keep), p, sites["drop1"].seed)
+        h = self.norm1(h)
+        ffk = pick(sites["ff"].keep)
+        ff = F.linear(h, self.linear1.weight, self.linear1.bias, L.ACT_RELU_DROPOUT,
+                      None if ffk is None else ffk.reshape(h.shape[0], -1).float(), p, sites["ff"].seed)
+        ff = self.linear2(ff)
+        out = self.norm2(F.dropout_add(h, ff, pick(sites["drop2"].keep), p, sites["drop2"].seed))
+        return out if last_only else out.view(B, T, d)
+
+
+class _EncoderStack(nn.Module):
+    """Holds ``layers`` under the attribute path nn.TransformerEncoder uses."""
+
+    def __init__(self, d_model, nhead, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([TransformerEncoderLayer(d_model, nhead) for _ in range(num_layers)])
+
+
+class TransformerEncoder(nn.Module):
+    """mixture-vae-transformer.py:35-55: embedding -> encoder stack -> last position -> four heads
+    (scale = exp(.), shape not clamped)."""
+
+    def __init__(self, input_dim, d_model, num_layers, nhead, latent_dim):
+        super().__init__()
+        self.embedding = Linear(input_dim, d_model)
+        self.transformer_encoder = _EncoderStack(d_model, nhead, num_layers)
+        self.mean_layer_normal = Linear(d_model, latent_dim)
+        self.logvar_layer_normal = Linear(d_model, latent_dim)
+        self.scale_layer_extreme = Linear(d_model, latent_dim)
+        self.shape_layer_extreme = Linear(d_model, latent_dim)
+
+    def forward(self, x, noise: Noise = None):
+        B, T, C = x.shape
+        h = self.embedding(x.reshape(B * T, C)).view(B, T, -1)
+        layers = self.transformer_encoder.layers
+        for i, layer in enumerate(layers):
+            h = layer(h, i, noise, last_only=(i == len(layers) - 1))
+        return (self.mean_layer_normal(h), self.logvar_layer_normal(h),
+                self.scale_layer_extreme(h, act=L.ACT_EXP), self.shape_layer_extreme(h))
+
+
+class TransformerDecoder(nn.Module):
+    """mixture-vae-transformer.py:57-72 (dense1 is registered and never used, as there)."""
+
+    def __init__(self, latent_dim, future_steps):
+        super().__init__()
+        self.dense1 = Linear(latent_dim, 500)
+        self.fc1 = Linear(latent_dim, 128)
+        self.fc2 = Linear(128, 500)
+        self.out = Linear(500, future_steps)
+        self.final_fcn = Linear(future_steps, future_steps)
+
+    def forward(self, z, noise: Noise = None):
+        z = self.fc1(z, act=L.ACT_RELU)
+        site = _Site(noise, "dec_keep", self.training)
+        keep = None if site.keep is None else site.keep.float()
+        z = F.linear(z, self.fc2.weight, self.fc2.bias, L.ACT_RELU_DROPOUT, keep, TRANSFORMER_DROP_P, site.seed)
+        return self.final_fcn(self.out(z))
+
+
+class TransformerMixtureVAE(nn.Module):
+    """mixture-vae-transformer.py:74-113.  ``loss_function`` takes the threshold as its last argument, as
+    the reference's does."""
+    kind = "transformer"
+
+    def __init__(self, input_dim, d_model, num_layers, nhead, latent_dim, future_steps, beta=1.0):
+        super().__init__()
+        self.encoder = TransformerEncoder(input_dim, d_model, num_layers, nhead, latent_dim)
+        self.decoder = TransformerDecoder(latent_dim, future_steps)
+        self.beta = beta
+        self.threshold = None   # train_step passes model.threshold when it is set
+        self.pi_params = nn.Parameter(torch.tensor([3.0, 0.01]))
+
+    def reparameterize(self, mean, logvar, scale, shape, choice=None, eps=None, u=None):
+        return F.reparameterize_mixture(mean, logvar, scale, shape, self.pi_params, choice, eps, u)
+
+    def forward(self, x, noise: Noise = None):
+        mean, logvar, scale, shape = self.encoder(x, noise)
+        n = noise or {}
+        z = F.reparameterize_mixture(mean, logvar, scale, shape, self.pi_params, n.get("choice"), n.get("eps"),
+                                     n.get("u"))
+        return self.decoder(z, noise), mean, logvar, scale, shape
+
+    def loss_function(self, reconstructed, y, mean, logvar, scale, shape, threshold=None):
+        thr = self.threshold if threshold is None else threshold
+        if thr is None:
+            raise ValueError("TransformerMixtureVAE.loss_function needs a threshold")
+        return F.mixture_split_elbo(reconstructed, y, mean, logvar, scale, shape, self.pi_params, thr, self.beta)
+
+
 def build_model(kind: str, input_dim: int, lstm_output_dim: int, latent_dim: int, future_steps: int = 1,
                 beta: float = 0.001, threshold: float = 95.0) -> nn.Module:
     if kind == "gaussian":
