@@ -39,7 +39,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="mixture", choices=["gaussian", "gpd", "mixture"])
+    ap.add_argument("--model", default="mixture", choices=["gaussian", "gpd", "mixture", "transformer"],
+                    help="the three LSTM-VAE families (headline: mixture) or the transformer-encoder mixture VAE")
+    ap.add_argument("--d-model", type=int, default=64)
+    ap.add_argument("--nhead", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU")
     ap.add_argument("--T", type=int, default=96)
     ap.add_argument("--C", type=int, default=370)
@@ -166,6 +170,144 @@ def elbo_hbm_roofline(dev, rows=1 << 20, Ld=32, iters=10):
                     "algorithmic bytes = rows * (72*L + 16)"}
 
 
+def transformer_flops(B, T, C, d, layers, dff=2048):
+    """Dense FLOPs of one train step of the transformer variant as the reference states it (every
+    position through every layer): forward 2*rows*N*K per product, backward twice that (data and
+    weight gradients; the embedding's input needs none), attention 4*T*T*d forward, 2.5x backward."""
+    rows = B * T
+    fwd = 2.0 * rows * C * d
+    bwd = 2.0 * rows * C * d
+    per_layer = 2.0 * rows * d * 3 * d + 2.0 * rows * d * d + 4.0 * rows * d * dff
+    attn = 4.0 * B * T * T * d
+    fwd += layers * (per_layer + attn)
+    bwd += layers * (2 * per_layer + 2.5 * attn)
+    return fwd + bwd
+
+
+def cpu_baseline_transformer(T, C, d, nhead, layers, Ld, sample, budget_s=20.0):
+    """The reference's CPU path for the transformer variant restated by oracle/ref_transformer.py
+    (stock torch CPU ops + autograd + Adam) on a bounded sample of the same workload."""
+    from oracle import ref_torch as R
+    from oracle import ref_transformer as RT
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    sd = RT.init_state(C, d, layers, Ld, 1, seed=0)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(sample, T, C, generator=g)
+    y = torch.randn(sample, 1, generator=g)
+    thr = float(y.abs().median())
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in sd.items()}
+
+    def one(step):
+        noise = RT.draw_noise(sample, T, d, nhead, layers, Ld, seed=step)
+        _, _, grads = RT.loss_and_grads(sd, x, y, noise, nhead, thr)
+        R.adam_step(sd, grads, m, v, step, 1e-3)
+
+    one(1)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": sample * n / el, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of {sample} windows x {T} x {C} (same model, fp32, torch {torch.__version__} CPU "
+                      f"ops + autograd + Adam, every position through every layer as the reference does), {el:.1f} s"}
+
+
+def bench_transformer(a, dev, world, rank, launched):
+    """--model transformer: the transformer-encoder mixture VAE (vae-models/mixture-vae-transformer.py) on the
+    same LD2011-shaped windows.  Same step definition and JSON contract as the LSTM models."""
+    import vts
+    from vts import _lib as L
+
+    vts.set_mode(a.mode)
+    torch.manual_seed(1234)
+    model = vts.TransformerMixtureVAE(a.C, a.d_model, a.layers, a.nhead, a.L, 1).to(dev)
+    model.train()
+    trainer = vts.DataParallelTrainer(model, lr=1e-3)
+    torch.manual_seed(4321 + rank)
+    x, y = synth_windows(a.batch, a.T, a.C, rank, dev)
+    model.threshold = float(y.abs().median())    # both selections of the loss populated on every rank
+
+    def sync():
+        if launched:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(x, y)
+    sync()
+    L.timer.enabled = True
+    L.timer.reset()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = trainer.step(x, y)
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.timer.enabled = False
+    if launched:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+    if rank != 0:
+        return
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = world * a.batch * a.steps / elapsed
+    summ = L.timer.summary()
+    kernels = {}
+    for name, (n, tot_ms) in summ.items():
+        avg_ms = tot_ms / n
+        kernels[name] = {"launches_per_step": n // a.steps, "avg_ms": round(avg_ms, 4),
+                         "share_of_step": round(tot_ms / a.steps / ms_per_step, 4)}
+        if name.startswith("linear_"):
+            dims = name.split()[1].split("x")
+            M, N, K = [int(v) for v in dims]
+            mult = 2.0 if name.startswith("linear_fwd") or name.endswith("nodx") else 4.0
+            kernels[name]["tflops"] = round(mult * M * N * K / (avg_ms * 1e-3) / 1e12, 2)
+    dom = max((k for k in kernels if "tflops" in kernels[k]), key=lambda k: summ[k][1])
+    dom_tflops = kernels[dom]["tflops"]
+    split = a.mode == "bf16x3"
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round((3 if split else 1) * dom_tflops, 2),
+                "peak": PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "algorithmic_tflops": dom_tflops,
+                "note": "dense product FLOPs of the entry point (2*M*N*K forward; data + weight gradient backward) / its "
+                        "device time (HIP events on the launch stream)" +
+                        ("; three bf16 matrix-core products are executed per fp32 product" if split else "")}
+    roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
+    total = transformer_flops(a.batch, a.T, a.C, a.d_model, a.layers)
+    out = {
+        "metric": "train windows/sec (fwd+bwd+ELBO+Adam)", "value": round(value, 1), "unit": "windows/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if not split else "bf16x3 (fp32 operands split into two bf16, three bf16 MFMA products per "
+                                         "fp32 product, fp32 accumulate) in the large Linear products; f32 elsewhere",
+        "data": "synthetic",
+        "config": {"workload": f"transformer-encoder mixture VAE train step, LD2011-shaped windows: {a.batch} windows/GPU x "
+                               f"{a.T} steps x {a.C} channels, d_model {a.d_model}, {a.nhead} heads, {a.layers} layers, "
+                               f"dim_feedforward 2048, latent {a.L}, future_steps 1",
+                   "model_kind": "transformer", "windows_per_gpu": a.batch, "global_batch": a.batch * world,
+                   "parallelism": f"dp{world}", "gemm_mode": a.mode, "optimizer": "Adam(lr=1e-3) inside the timed step",
+                   "noise": "sampling noise drawn on device every step; dropout masks from the counter hash, fresh seeds every step",
+                   "last_layer": "final encoder layer evaluated for the last position only (the only one the model reads)"},
+        "roofline": roofline,
+        "step_mfma": {"reference_algorithm_tflop_per_step": round(total / 1e12, 4),
+                      "note": "FLOPs of the step as the reference runs it (all positions through all layers); the "
+                              "last-position-only final layer executes about half of them"},
+        "kernels": kernels,
+        "final_loss": final_loss,
+    }
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_transformer(a.T, a.C, a.d_model, a.nhead, a.layers, a.L,
+                                                       min(a.cpu_sample, 64))
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,6 +328,12 @@ def main():
     import vts
     from vts import _lib as L
 
+    if a.model == "transformer":
+        bench_transformer(a, dev, world, rank, launched)
+        if launched:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     vts.set_mode(a.mode)
     torch.manual_seed(1234)                     # identical replicas on every rank
     model = vts.build_model(a.model, a.C, a.H, a.L, 1).to(dev)

@@ -164,11 +164,11 @@ class _Linear(torch.autograd.Function):
         scale = 1.0 / (1.0 - drop_p)
         if act == L.ACT_RELU_DROPOUT and keep is None:
             # mask from the library's counter hash: nothing but y is needed for backward
-            L.check(L.timer.call("linear_relu_dropout_fwd", lib.vts_linear_relu_dropout_fwd, L.ptr(x), x.stride(0),
+            L.check(L.timer.call(f"linear_fwd {M}x{N}x{K}", lib.vts_linear_relu_dropout_fwd, L.ptr(x), x.stride(0),
                                  L.ptr(weight), L.ptr(_c(bias)), L.ptr(y), M, N, K, drop_p, seed, _MODE, L.stream()),
                     "vts_linear_relu_dropout_fwd")
         else:
-            L.check(L.timer.call("linear_fwd", lib.vts_linear_fwd, L.ptr(x), x.stride(0), L.ptr(weight),
+            L.check(L.timer.call(f"linear_fwd {M}x{N}x{K}", lib.vts_linear_fwd, L.ptr(x), x.stride(0), L.ptr(weight),
                                  L.ptr(_c(bias)), L.ptr(y), M, N, K, act, L.ptr(keep), scale, L.ptr(aux), _MODE,
                                  L.stream()), "vts_linear_fwd")
         ctx.act = act
@@ -189,7 +189,7 @@ class _Linear(torch.autograd.Function):
         db = torch.empty(N, device=x.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.vts_linear_bwd_workspace_bytes(M, N, K)
         ws = L.workspace(ws_bytes, x.device)
-        L.check(L.timer.call("linear_bwd", lib.vts_linear_bwd, L.ptr(dy), L.ptr(y), L.ptr(aux), ctx.act, ctx.scale,
+        L.check(L.timer.call(f"linear_bwd {M}x{N}x{K}" + ("" if dx is not None else " nodx"), lib.vts_linear_bwd, L.ptr(dy), L.ptr(y), L.ptr(aux), ctx.act, ctx.scale,
                              L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(dx), K, 0, L.ptr(dw), L.ptr(db), 0,
                              L.wptr(ws), ws_bytes, M, N, K, _MODE, L.stream()), "vts_linear_bwd")
         return dx, dw, db, None, None, None, None
