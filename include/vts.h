@@ -137,6 +137,17 @@ int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, f
                    size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
                    vts_stream_t stream);
 
+/* vts_linear_bwd for a layer whose input x is itself the output of a fused relu (x_act = VTS_ACT_RELU) or
+ * relu+dropout (VTS_ACT_RELU_DROPOUT, kept elements scaled by x_act_scale): dx then holds the gradient
+ * w.r.t. that activation's INPUT, dx = x != 0 ? (dy . w) * scale : 0, applied in the GEMM epilogue.  This is
+ * linear2 -> dropout(relu(linear1)) of the encoder layer's feed-forward block without a separate pass over
+ * the [tokens, 2048] gradient.  x_act = VTS_ACT_NONE is vts_linear_bwd. */
+int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act, float keep_scale, const float* x,
+                      int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate, float* dw,
+                      float* db, int param_accumulate, int x_act, float x_act_scale, void* workspace,
+                      size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
+                      vts_stream_t stream);
+
 /* act = VTS_ACT_RELU_DROPOUT with the mask drawn by the library's counter hash instead of fed in:
  * element (row, col) is kept iff hash(seed, row*N + col) >= drop_p * 2^32 and scaled by 1/(1-drop_p);
  * seed 0 or drop_p 0 = eval mode (plain relu).  Backward is vts_linear_bwd with VTS_ACT_RELU_DROPOUT and

@@ -35,6 +35,7 @@ constexpr int BM = 128, BN = 128, BKT = 16;
 constexpr int NSUB = VTS_GEMM_NSUB;          // 16-deep k sub-chunks staged per barrier
 constexpr int BKS = BKT * NSUB;              // k elements per main-loop iteration
 constexpr size_t GEMM_LDS_BYTES = 2ul * NSUB * 2 * BKT * 144 * sizeof(float);
+static_assert(GEMM_LDS_BYTES >= 4 * 16 * 68 * sizeof(float), "row-major epilogue stages 4 x [16][68] floats in LDS");
 constexpr int LDS_LD = 144;  // 144 % 32 == 16: the (k, k+1) x 16-column b32 fragment reads hit 32 distinct banks
 
 struct GemmParams {
@@ -55,6 +56,9 @@ struct GemmParams {
   float keep_scale;
   unsigned long long drop_seed;   // act 4 without a keep mask: counter-hash dropout over index row*N + col
   unsigned drop_thresh;           // (0 = none: plain relu)
+  const float* mask_src;  // [M][N] (row stride ld_mask) or null: result = mask_src != 0 ? result * mask_scale : 0,
+  long ld_mask;           // i.e. the gradient of a relu(+dropout) whose OUTPUT is mask_src, applied to a data gradient
+  float mask_scale;
   float* aux;          // act 3: [M][N] 1.0 where pre-activation >= 1e-6 (gradient passes)
   int accumulate;      // C += result (ksplit == 1 only)
   int ksplit;          // >1: grid.z slabs of M*N floats at C
@@ -255,7 +259,7 @@ __device__ __forceinline__ bool map_workgroup(const GemmParams& P, int& m0, int&
 // v_mfma 16x16 C/D layout (lane l: column l&15, rows 4*(l>>4)..+3), the same for every dtype.
 template <int CK>
 __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4], int m0, int n0, int zslice,
-                                         int wm, int wn, int lane) {
+                                         int wm, int wn, int lane, float* stage) {
   const int r = lane & 15, g = lane >> 4;
   if constexpr (CK == C_T16) {
 #pragma unroll
@@ -280,41 +284,101 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
       }
     }
   } else {
+    // Row-major output.  In the accumulator layout a store instruction would touch 16 consecutive
+    // floats of four different rows; instead each wave passes one 16-row block at a time through a
+    // private LDS patch ([16][64] floats, row pitch 68) and writes it back out as float4 per lane:
+    // 16 lanes cover 256 contiguous bytes of a row, and bias, activation, dropout and the masks are
+    // applied on that side with vector loads.  The k loop ended with a workgroup barrier, so the
+    // operand tiles in LDS are dead.
     float* Cbase = P.C + (P.ksplit > 1 ? (long)zslice * P.M * P.N : 0);
     const long ldc = (P.ksplit > 1) ? P.N : P.ldc;
+    const bool plain = P.ksplit > 1;
+    constexpr int SP = 68;
+    float* patch = stage + (wm * 2 + wn) * (16 * SP);
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cbase) & 15) == 0) &&
+                        (!P.keep || (reinterpret_cast<uintptr_t>(P.keep) & 15) == 0) &&
+                        (!P.aux || (reinterpret_cast<uintptr_t>(P.aux) & 15) == 0) &&
+                        (!P.mask_src || ((reinterpret_cast<uintptr_t>(P.mask_src) & 15) == 0 && (P.ld_mask & 3) == 0));
+    const int c4 = (lane & 15) * 4;
+    const int col0 = n0 + wn * 64 + c4;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!plain) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (col0 + e < P.N) {
+          if (P.bias0) bias4[e] += P.bias0[col0 + e];
+          if (P.bias1) bias4[e] += P.bias1[col0 + e];
+        }
+      }
+    }
+    auto finish = [&](float v, long off, int row, int col) -> float {   // off = row * ldc + col
+      if (P.act == 1) v = fmaxf(v, 0.f);
+      else if (P.act == 2) v = expf(v);
+      else if (P.act == 3) {
+        if (P.aux) P.aux[off] = (v >= 1e-6f) ? 1.f : 0.f;
+        v = fmaxf(v, 1e-6f);
+      } else if (P.act == 4) {
+        v = fmaxf(v, 0.f);
+        if (P.keep) v = v * P.keep[off] * P.keep_scale;
+        else if (P.drop_thresh)
+          v = vts_hash32(P.drop_seed, (unsigned long long)row * P.N + col) >= P.drop_thresh ? v * P.keep_scale : 0.f;
+      }
+      if (P.mask_src) v = (P.mask_src[(long)row * P.ld_mask + col] != 0.f) ? v * P.mask_scale : 0.f;
+      if (P.accumulate) v += Cbase[off];
+      return v;
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + r;
-        if (col >= P.N) continue;
-        float bsum = 0.f;
-        if (P.ksplit == 1) {
-          if (P.bias0) bsum += P.bias0[col];
-          if (P.bias1) bsum += P.bias1[col];
-        }
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = m0 + wm * 64 + i * 16 + 4 * g + reg;
-          if (row >= P.M) continue;
-          float v = acc[i][j][reg] + bsum;
-          if (P.ksplit == 1) {
-            if (P.act == 1) v = fmaxf(v, 0.f);
-            else if (P.act == 2) v = expf(v);
-            else if (P.act == 3) {
-              if (P.aux) P.aux[(long)row * ldc + col] = (v >= 1e-6f) ? 1.f : 0.f;
-              v = fmaxf(v, 1e-6f);
-            } else if (P.act == 4) {
-              v = fmaxf(v, 0.f);
-              if (P.keep) v = v * P.keep[(long)row * ldc + col] * P.keep_scale;
-              else if (P.drop_thresh)
-                v = vts_hash32(P.drop_seed, (unsigned long long)row * P.N + col) >= P.drop_thresh ? v * P.keep_scale : 0.f;
-            }
-            if (P.accumulate) v += Cbase[(long)row * ldc + col];
+        for (int reg = 0; reg < 4; ++reg) patch[(4 * g + reg) * SP + j * 16 + r] = acc[i][j][reg];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + i * 16 + rl;
+        f32x4 v = *reinterpret_cast<const f32x4*>(patch + rl * SP + c4);
+        if (row >= P.M || col0 >= P.N) continue;
+        const long off = (long)row * ldc + col0;
+        if (plain) {
+          if (vec_ok && col0 + 3 < P.N) *reinterpret_cast<f32x4*>(Cbase + off) = v;
+          else
+            for (int e = 0; e < 4; ++e)
+              if (col0 + e < P.N) Cbase[off + e] = v[e];
+          continue;
+        }
+        v += bias4;
+        if (vec_ok && col0 + 3 < P.N && P.act != 3 && !(P.act == 4 && P.keep == nullptr && P.drop_thresh)) {
+          // vector forms of the element transforms (clamp-with-aux and hashed dropout take the scalar path below)
+          if (P.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          else if (P.act == 2) { v[0] = expf(v[0]); v[1] = expf(v[1]); v[2] = expf(v[2]); v[3] = expf(v[3]); }
+          else if (P.act == 4) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            if (P.keep) v = v * *reinterpret_cast<const f32x4*>(P.keep + off) * P.keep_scale;
           }
-          Cbase[(long)row * ldc + col] = v;
+          if (P.mask_src) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(P.mask_src + (long)row * P.ld_mask + col0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (mk[e] != 0.f) ? v[e] * P.mask_scale : 0.f;
+          }
+          if (P.accumulate) v += *reinterpret_cast<const f32x4*>(Cbase + off);
+          *reinterpret_cast<f32x4*>(Cbase + off) = v;
+        } else if (vec_ok && col0 + 3 < P.N && P.act == 4) {
+          // hashed dropout: element hashes, one vector store
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = finish(v[e], off + e, row, col0 + e);
+          *reinterpret_cast<f32x4*>(Cbase + off) = v;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (col0 + e < P.N) Cbase[off + e] = finish(v[e], off + e, row, col0 + e);
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     }
   }
 }
@@ -395,7 +459,7 @@ __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmP
     __syncthreads();
   }
 
-  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane);
+  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane, lds_raw);
 }
 
 // =================================================================================================
@@ -433,6 +497,7 @@ __device__ __forceinline__ int lds3_off(int row, int kbyte) {
 constexpr int NSUB3 = VTS_GEMM3_NSUB;   // 32-deep k sub-chunks staged per barrier pair
 constexpr bool PIPE3 = VTS_GEMM3_PIPE;  // software-pipelined k loop (two LDS buffers) or one buffer and more workgroups per CU
 constexpr size_t GEMM3_LDS_BYTES = (PIPE3 ? 2ul : 1ul) * 4ul * PLANE * NSUB3;   // per buffer: A hi, A lo, B hi, B lo
+static_assert(GEMM3_LDS_BYTES >= 4 * 16 * 68 * sizeof(float), "row-major epilogue stages 4 x [16][68] floats in LDS");
 
 __device__ __forceinline__ void load4(const float* __restrict__ p, int nvalid, float (&v)[4]) {
   if (nvalid >= 4) {
@@ -790,7 +855,7 @@ __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const G
       vts_lds_barrier();
     }
   }
-  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane);
+  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane, reinterpret_cast<float*>(lds3));
 }
 
 // Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C.
@@ -944,9 +1009,11 @@ int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* b
 
 // dX[M][K] (+)= dY[M][N] . W[N][K]
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
-                       int accumulate, int mode, hipStream_t stream) {
+                       int accumulate, const float* mask_src, long ld_mask, float mask_scale, int mode,
+                       hipStream_t stream) {
   GemmParams P{};
   P.mode = mode;
+  P.mask_src = mask_src; P.ld_mask = ld_mask; P.mask_scale = mask_scale;
   P.A = dY; P.B = W; P.C = dX;
   P.M = M; P.N = K; P.K = N;
   P.lda = lddy; P.ldb = K; P.ldc = lddx;

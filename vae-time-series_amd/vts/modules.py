@@ -306,9 +306,8 @@ class TransformerEncoderLayer(nn.Module):
         h = F.dropout_add(res, sa.out_proj(att), pick(sites["drop1"].keep), p, sites["drop1"].seed)
         h = self.norm1(h)
         ffk = pick(sites["ff"].keep)
-        ff = F.linear(h, self.linear1.weight, self.linear1.bias, L.ACT_RELU_DROPOUT,
-                      None if ffk is None else ffk.reshape(h.shape[0], -1).float(), p, sites["ff"].seed)
-        ff = self.linear2(ff)
+        ff = F.feed_forward(h, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                            None if ffk is None else ffk.reshape(h.shape[0], -1).float(), p, sites["ff"].seed)
         out = self.norm2(F.dropout_add(h, ff, pick(sites["drop2"].keep), p, sites["drop2"].seed))
         return out if last_only else out.view(B, T, d)
 
