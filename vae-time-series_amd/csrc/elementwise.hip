@@ -465,6 +465,101 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int j = threadIdx.x; j < 2 * H; j += blockDim.x) part[(long)blockIdx.x * 2 * H + j] = sm[j];
 }
 
+// Narrow rows (H = 4 * LPR <= 64, the transformer's d_model): LPR lanes share a row with one float4
+// each, so a wave covers 64/LPR rows per load instruction instead of one, the row statistics are
+// xor-shuffles inside the lane group, and the gamma/beta gradients accumulate in registers (each lane
+// always sees the same four columns) with one cross-lane and one LDS reduction at the end.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_narrow_kernel(const float* __restrict__ x, long ldx,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   float* __restrict__ y, float* __restrict__ mean,
+                                                                   float* __restrict__ rstd, int M, float eps) {
+  constexpr int H = 4 * LPR, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, slot = lane / LPR;
+  const int row = (blockIdx.x * 4 + wave) * RPW + slot;
+  const bool valid = row < M;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (valid) v = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + sub * 4);
+  const float mu = group_sum<LPR>((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / H);
+  const f32x4 d = v - mu;
+  const float var = group_sum<LPR>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / H);
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (!valid) return;
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + sub * 4);
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + sub * 4);
+  *reinterpret_cast<f32x4*>(y + (long)row * H + sub * 4) = d * rs * g4 + b4;
+  if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const float* __restrict__ dy,
+                                                                   const float* __restrict__ x, long ldx,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd,
+                                                                   float* __restrict__ dx, long lddx,
+                                                                   float* __restrict__ part, int M,
+                                                                   int rows_per_block) {
+  constexpr int H = 4 * LPR, RPW = 64 / LPR;
+  __shared__ float sm[4][2][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, slot = lane / LPR;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + sub * 4);
+  f32x4 dg = f32x4{0.f, 0.f, 0.f, 0.f}, db = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int base = r0 + wave * RPW; base < r1; base += 4 * RPW) {
+    const int row = base + slot;
+    const bool valid = row < r1;
+    f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, dyv = xv;
+    float mu = 0.f, rs = 0.f;
+    if (valid) {
+      xv = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + sub * 4);
+      dyv = *reinterpret_cast<const f32x4*>(dy + (long)row * H + sub * 4);
+      mu = mean[row]; rs = rstd[row];
+    }
+    const f32x4 xh = (xv - mu) * rs;
+    const f32x4 dxh = dyv * g4;
+    const float s1 = group_sum<LPR>((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.0f / H);
+    const f32x4 t = dxh * xh;
+    const float s2 = group_sum<LPR>((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / H);
+    if (valid) {
+      *reinterpret_cast<f32x4*>(dx + (long)row * lddx + sub * 4) = (dxh - s1 - xh * s2) * rs;
+      dg += dyv * xh;
+      db += dyv;
+    }
+  }
+  // lanes with the same `sub` hold the same columns: fold the row slots, then the four waves
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[e] += __shfl_xor(dg[e], o); db[e] += __shfl_xor(db[e], o); }
+  }
+  if (slot == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sm[wave][0][sub * 4 + e] = dg[e]; sm[wave][1][sub * 4 + e] = db[e]; }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * H; j += blockDim.x) {
+    const int which = j / H, col = j % H;
+    part[(long)blockIdx.x * 2 * H + j] = (sm[0][which][col] + sm[1][which][col]) + (sm[2][which][col] + sm[3][which][col]);
+  }
+}
+
+static bool ln_narrow_ok(const void* a, const void* b, const void* c, long ld0, long ld1, int H) {
+  return (H == 16 || H == 32 || H == 64) && (ld0 % 4) == 0 && (ld1 % 4) == 0 && vts_aligned16(a) && vts_aligned16(b) &&
+         vts_aligned16(c);
+}
+
 // -------------------------------------------------------------------------- activation gradient
 // kind 1 relu: dy*(y>0) | 2 exp: dy*y | 3 clamp: dy*aux | 4 relu+dropout: dy*scale*(y!=0)
 __global__ void act_bwd_kernel(int kind, const float* __restrict__ dy, const float* __restrict__ y,
@@ -711,6 +806,15 @@ int vts_ew_elbo_bwd(int kind, const float* recon, const float* y, const float* m
 
 int vts_ew_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, float* mean,
                          float* rstd, int M, int H, float eps, hipStream_t st) {
+  if (ln_narrow_ok(x, y, gamma, ldx, H, H) && vts_aligned16(beta)) {
+    const int rpw = 256 / H;   // rows per wave
+    const dim3 grid(vts_cdiv(M, 4 * rpw));
+    if (H == 64) hipLaunchKernelGGL(layernorm_fwd_narrow_kernel<16>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, M, eps);
+    else if (H == 32) hipLaunchKernelGGL(layernorm_fwd_narrow_kernel<8>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, M, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_narrow_kernel<4>, grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, M, eps);
+    VTS_CHECK_LAUNCH("layernorm_fwd_narrow");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(vts_cdiv(M, 4)), dim3(256), 0, st, x, ldx, gamma, beta, y, mean,
                      rstd, M, H, eps);
   VTS_CHECK_LAUNCH("layernorm_fwd");
@@ -719,7 +823,7 @@ int vts_ew_layernorm_fwd(const float* x, long ldx, const float* gamma, const flo
 
 int vts_ew_layernorm_bwd_blocks(int M) {
   int b = vts_cdiv(M, 64);
-  if (b > 256) b = 256;
+  if (b > 1024) b = 1024;
   return b < 1 ? 1 : b;
 }
 
@@ -727,6 +831,13 @@ int vts_ew_layernorm_bwd(const float* dy, const float* x, long ldx, const float*
                          const float* rstd, float* dx, long lddx, float* part, int M, int H, hipStream_t st) {
   const int blocks = vts_ew_layernorm_bwd_blocks(M);
   const int rpb = vts_cdiv(M, blocks);
+  if (ln_narrow_ok(x, dy, dx, ldx, lddx, H) && vts_aligned16(gamma)) {
+    if (H == 64) hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<16>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
+    else if (H == 32) hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<8>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
+    else hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<4>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
+    VTS_CHECK_LAUNCH("layernorm_bwd_narrow");
+    return VTS_OK;
+  }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * H * sizeof(float), st, dy, x, ldx, gamma,
                      mean, rstd, dx, lddx, part, M, H, rpb);
   VTS_CHECK_LAUNCH("layernorm_bwd");

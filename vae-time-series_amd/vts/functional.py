@@ -282,8 +282,8 @@ class _LayerNorm(torch.autograd.Function):
         mean = torch.empty(M, device=x.device, dtype=torch.float32)
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
         gamma, beta = gamma.contiguous(), beta.contiguous()
-        L.check(lib.vts_layernorm_fwd(L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean),
-                                      L.ptr(rstd), M, H, eps, L.stream()), "vts_layernorm_fwd")
+        L.check(L.timer.call("layernorm_fwd", lib.vts_layernorm_fwd, L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(beta),
+                             L.ptr(y), L.ptr(mean), L.ptr(rstd), M, H, eps, L.stream()), "vts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
 
@@ -298,9 +298,9 @@ class _LayerNorm(torch.autograd.Function):
         dbeta = torch.empty(H, device=x.device, dtype=torch.float32)
         ws_bytes = lib.vts_layernorm_bwd_workspace_bytes(M, H)
         ws = L.workspace(ws_bytes, x.device)
-        L.check(lib.vts_layernorm_bwd(L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
-                                      L.ptr(dx), H, L.ptr(dgamma), L.ptr(dbeta), 0, L.wptr(ws), ws_bytes, M, H,
-                                      L.stream()), "vts_layernorm_bwd")
+        L.check(L.timer.call("layernorm_bwd", lib.vts_layernorm_bwd, L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(gamma),
+                             L.ptr(mean), L.ptr(rstd), L.ptr(dx), H, L.ptr(dgamma), L.ptr(dbeta), 0, L.wptr(ws),
+                             ws_bytes, M, H, L.stream()), "vts_layernorm_bwd")
         return dx, dgamma, dbeta, None
 
 
