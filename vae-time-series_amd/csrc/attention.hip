@@ -185,6 +185,84 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const MhaParams P) {
   }
 }
 
+// One query per window (Tq == 1, the last-position-only layer): lanes own keys, the softmax
+// statistics and the DH-wide sums are wave reductions, nothing is staged in LDS.
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void mha_fwd_one_kernel(const MhaParams P) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long item = (long)blockIdx.x * 4 + wave;
+  if (item >= (long)P.B * P.nhead) return;
+  const int b = (int)(item / P.nhead), h = (int)(item % P.nhead);
+  float q[DH];
+  load_row<DH>(P.q + (long)b * P.ldq + h * DH, q);
+#pragma unroll
+  for (int c = 0; c < DH; ++c) q[c] *= P.scale;
+  const float* kb = P.k + (long)b * P.T * P.ldkv + h * DH;
+  const float* vb = P.v + (long)b * P.T * P.ldkv + h * DH;
+  float m = -INFINITY;
+  for (int j = lane; j < P.T; j += 64) m = fmaxf(m, dot<DH>(q, kb + (long)j * P.ldkv));
+  m = wave_max_f(m);
+  float l = 0.f, acc[DH];
+#pragma unroll
+  for (int c = 0; c < DH; ++c) acc[c] = 0.f;
+  for (int j = lane; j < P.T; j += 64) {
+    const float p = __expf(dot<DH>(q, kb + (long)j * P.ldkv) - m);
+    l += p;
+    axpy<DH>(p * P.drop.mult((unsigned long long)item * P.T + j), vb + (long)j * P.ldkv, acc);
+  }
+  l = wave_sum_f(l);
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int c = 0; c < DH; ++c) acc[c] = wave_sum_f(acc[c]) * inv;
+  if (lane == 0) {
+    store_row<DH>(P.out + (long)b * P.ldo + h * DH, acc);
+    P.lse[item] = m + __logf(l);
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void mha_bwd_one_kernel(const MhaParams P) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long item = (long)blockIdx.x * 4 + wave;
+  if (item >= (long)P.B * P.nhead) return;
+  const int b = (int)(item / P.nhead), h = (int)(item % P.nhead);
+  float q[DH], g[DH], dq[DH];
+  load_row<DH>(P.q + (long)b * P.ldq + h * DH, q);
+  load_row<DH>(P.dout + (long)b * P.lddo + h * DH, g);
+  const float D = dot<DH>(g, P.out + (long)b * P.ldo + h * DH);
+  const float lse = P.lse[item];
+#pragma unroll
+  for (int c = 0; c < DH; ++c) { q[c] *= P.scale; dq[c] = 0.f; }
+  const long kvrow = (long)b * P.T;
+  for (int j = lane; j < P.T; j += 64) {
+    const float* kj = P.k + (kvrow + j) * P.ldkv + h * DH;
+    const float* vj = P.v + (kvrow + j) * P.ldkv + h * DH;
+    const float p = __expf(dot<DH>(q, kj) - lse);
+    const float mult = P.drop.mult((unsigned long long)item * P.T + j);
+    const float ds = p * (mult * dot<DH>(g, vj) - D);
+    axpy<DH>(ds, kj, dq);
+    float dk[DH], dv[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) { dk[c] = ds * q[c]; dv[c] = p * mult * g[c]; }   // q already carries the scale
+    store_row<DH>(P.dk + (kvrow + j) * P.lddkv + h * DH, dk);
+    store_row<DH>(P.dv + (kvrow + j) * P.lddkv + h * DH, dv);
+  }
+#pragma unroll
+  for (int c = 0; c < DH; ++c) dq[c] = wave_sum_f(dq[c]) * P.scale;
+  if (lane == 0) store_row<DH>(P.dq + (long)b * P.lddq + h * DH, dq);
+}
+
 // out = residual + dropout(x)   /   dx = dropout mask applied to dout   /   the mask itself
 __global__ void dropout_add_kernel(const float* __restrict__ residual, const float* __restrict__ x, VtsDrop drop,
                                    float* __restrict__ out, long n) {
@@ -203,6 +281,13 @@ int grid_for(long n) {
 
 template <int DH>
 int launch_mha(const MhaParams& P, bool bwd, hipStream_t st) {
+  if (P.Tq == 1) {
+    const unsigned grid1 = (unsigned)(((long)P.B * P.nhead + 3) / 4);
+    if (bwd) hipLaunchKernelGGL(mha_bwd_one_kernel<DH>, dim3(grid1), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(mha_fwd_one_kernel<DH>, dim3(grid1), dim3(256), 0, st, P);
+    VTS_CHECK_LAUNCH("mha_one");
+    return VTS_OK;
+  }
   const size_t per_wave = bwd ? (size_t)2 * P.T * DH + (size_t)2 * P.Tq * DH + 2 * P.Tq : (size_t)2 * P.T * DH;
   const size_t bytes = 4 * per_wave * sizeof(float);
   if (bytes > 160 * 1024) {

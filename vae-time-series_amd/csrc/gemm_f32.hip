@@ -858,16 +858,38 @@ __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const G
   epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane, reinterpret_cast<float*>(lds3));
 }
 
-// Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C.
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
-                                    long ldc, int S, int accumulate) {
+// Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C.  A workgroup owns
+// 64 consecutive output elements; its 16 waves split the slabs (four loads in flight each) and
+// combine through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C,
+                                                            int M, int N, long ldc, int S, int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long total = (long)M * N;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[(long)z * total + idx];
-    const long row = idx / N, col = idx % N;
-    float* dst = C + row * ldc + col;
-    *dst = accumulate ? (*dst + s) : s;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long idx = base + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < total) {
+      const float* p0 = slabs + idx;
+      int z = wave;
+      for (; z + 48 < S; z += 64) {
+        s0 += p0[(long)z * total];
+        s1 += p0[(long)(z + 16) * total];
+        s2 += p0[(long)(z + 32) * total];
+        s3 += p0[(long)(z + 48) * total];
+      }
+      for (; z < S; z += 16) s0 += p0[(long)z * total];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && idx < total) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) s += red[w][lane];
+      float* dst = C + (idx / N) * ldc + idx % N;
+      *dst = accumulate ? (*dst + s) : s;
+    }
+    __syncthreads();
   }
 }
 
@@ -928,9 +950,9 @@ size_t vts_gemm_slab_bytes(int M, int N, int ksplit) {
 static int finish_split(GemmParams P, float* Cfinal, long ldc, int accumulate, hipStream_t stream) {
   if (P.ksplit <= 1) return VTS_OK;
   const long total = (long)P.M * P.N;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, P.C, Cfinal, P.M, P.N, ldc,
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(1024), 0, stream, P.C, Cfinal, P.M, P.N, ldc,
                      P.ksplit, accumulate);
   VTS_CHECK_LAUNCH("reduce_slabs");
   return VTS_OK;

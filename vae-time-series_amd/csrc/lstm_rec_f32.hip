@@ -421,21 +421,33 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
   }
 }
 
-// out[n] (+)= sum_p part[p * pitch + n].  One workgroup per 64 columns; its 4 waves split the
-// partials (coalesced 256-byte rows) and combine through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part,
-                                                              float* __restrict__ out, int nparts, int N,
-                                                              long pitch, int accumulate) {
-  __shared__ float red[4][64];
+// out[n] (+)= sum_p part[p * pitch + n].  One workgroup per 64 columns; its 16 waves split the
+// partials (coalesced 256-byte rows, four loads in flight per wave) and combine through LDS in a
+// fixed order (deterministic).
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part,
+                                                               float* __restrict__ out, int nparts, int N,
+                                                               long pitch, int accumulate) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (n < N)
-    for (int p = wave; p < nparts; p += 4) s += part[(long)p * pitch + n];
-  red[wave][lane] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    const float* p0 = part + n;
+    int p = wave;
+    for (; p + 48 < nparts; p += 64) {
+      s0 += p0[(long)p * pitch];
+      s1 += p0[(long)(p + 16) * pitch];
+      s2 += p0[(long)(p + 32) * pitch];
+      s3 += p0[(long)(p + 48) * pitch];
+    }
+    for (; p < nparts; p += 16) s0 += p0[(long)p * pitch];
+  }
+  red[wave][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (wave == 0 && n < N) {
-    const float tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w][lane];
     out[n] = accumulate ? out[n] + tot : tot;
   }
 }
@@ -506,7 +518,7 @@ int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const floa
 
 int vts_colsum_partials(const float* part, float* out, int nparts, int N, long pitch, int accumulate,
                         hipStream_t stream) {
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(vts_cdiv(N, 64)), dim3(256), 0, stream, part, out, nparts, N,
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(vts_cdiv(N, 64)), dim3(1024), 0, stream, part, out, nparts, N,
                      pitch, accumulate);
   VTS_CHECK_LAUNCH("colsum_partials");
   return VTS_OK;
