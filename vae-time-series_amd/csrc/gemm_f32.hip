@@ -257,11 +257,33 @@ __device__ __forceinline__ bool map_workgroup(const GemmParams& P, int& m0, int&
 
 // Accumulator tiles -> memory.  acc[i][j] is the 16x16 tile (i, j) of this wave's 64x64 block in the
 // v_mfma 16x16 C/D layout (lane l: column l&15, rows 4*(l>>4)..+3), the same for every dtype.
-template <int CK>
+// PLAIN: the launch has no bias, activation or mask (weight gradients, split-K slabs): a bare store
+// (or accumulate) straight from the accumulator layout, which keeps these kernels' register budget
+// for their operand streams.
+template <int CK, bool PLAIN>
 __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4], int m0, int n0, int zslice,
                                          int wm, int wn, int lane, float* stage) {
   const int r = lane & 15, g = lane >> 4;
-  if constexpr (CK == C_T16) {
+  if constexpr (CK == C_ROW && PLAIN) {
+    float* Cbase = P.C + (P.ksplit > 1 ? (long)zslice * P.M * P.N : 0);
+    const long ldc = (P.ksplit > 1) ? P.N : P.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r;
+        if (col >= P.N) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = m0 + wm * 64 + i * 16 + 4 * g + reg;
+          if (row >= P.M) continue;
+          float v = acc[i][j][reg];
+          if (P.ksplit == 1 && P.accumulate) v += Cbase[(long)row * ldc + col];
+          Cbase[(long)row * ldc + col] = v;
+        }
+      }
+    }
+  } else if constexpr (CK == C_T16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mt = (m0 + wm * 64 + i * 16) >> 4;
@@ -383,7 +405,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
   }
 }
 
-template <int AK, int BKIND, int CK>
+template <int AK, int BKIND, int CK, bool PLAIN>
 __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];   // [buf][sub][A|B][BKT * LDS_LD]
   auto lds = [&](int buf, int sub, int op) -> float* { return lds_raw + ((buf * NSUB + sub) * 2 + op) * (BKT * LDS_LD); };
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(256, VTS_GEMM_WPS) void gemm_f32_kernel(const GemmP
     __syncthreads();
   }
 
-  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane, lds_raw);
+  epilogue<CK, PLAIN>(P, acc, m0, n0, zslice, wm, wn, lane, lds_raw);
 }
 
 // =================================================================================================
@@ -724,7 +746,7 @@ __device__ __forceinline__ void store3(char* __restrict__ hi, char* __restrict__
 template <int AK> struct OpKindA { static constexpr int v = (AK == A_ROW) ? 0 : (AK == A_COL) ? 1 : (AK == A_T16) ? 2 : 3; };
 template <int BKIND> struct OpKindB { static constexpr int v = (BKIND == B_NK) ? 0 : 1; };
 
-template <int AK, int BKIND, int CK>
+template <int AK, int BKIND, int CK, bool PLAIN>
 __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) char lds3[];   // [sub][A hi | A lo | B hi | B lo]
   constexpr int OA = OpKindA<AK>::v, OB = OpKindB<BKIND>::v;
@@ -855,10 +877,23 @@ __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const G
       vts_lds_barrier();
     }
   }
-  epilogue<CK>(P, acc, m0, n0, zslice, wm, wn, lane, reinterpret_cast<float*>(lds3));
+  epilogue<CK, PLAIN>(P, acc, m0, n0, zslice, wm, wn, lane, reinterpret_cast<float*>(lds3));
 }
 
-// Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C.  A workgroup owns
+// Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C: few slabs of a
+// large output, one thread per element.
+__global__ void reduce_few_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
+                                        long ldc, int S, int accumulate) {
+  const long total = (long)M * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[(long)z * total + idx];
+    float* dst = C + (idx / N) * ldc + idx % N;
+    *dst = accumulate ? (*dst + s) : s;
+  }
+}
+
+// The same for many slabs of a small output (weight gradients contracted over ~10^5 rows).  A workgroup owns
 // 64 consecutive output elements; its 16 waves split the slabs (four loads in flight each) and
 // combine through LDS in a fixed order.
 __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C,
@@ -893,32 +928,44 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
   }
 }
 
-template <int AK, int BKIND, int CK>
-int launch3(const GemmParams& P, hipStream_t stream) {
+static bool plain_epilogue(const GemmParams& P) {
+  return !P.bias0 && !P.bias1 && P.act == 0 && !P.mask_src;
+}
+
+template <int AK, int BKIND, int CK, bool PLAIN>
+int launch3p(const GemmParams& P, hipStream_t stream) {
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
   static unsigned long long lds_done = 0;   // per instantiation
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_bf16x3_kernel<AK, BKIND, CK>), GEMM3_LDS_BYTES,
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_bf16x3_kernel<AK, BKIND, CK, PLAIN>), GEMM3_LDS_BYTES,
                                &lds_done, "gemm_bf16x3"))
     return rc;
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, BKIND, CK>), dim3((unsigned)nwg), dim3(256), GEMM3_LDS_BYTES, stream, P);
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, BKIND, CK, PLAIN>), dim3((unsigned)nwg), dim3(256), GEMM3_LDS_BYTES, stream, P);
   VTS_CHECK_LAUNCH("gemm_bf16x3");
+  return VTS_OK;
+}
+
+template <int AK, int BKIND, int CK, bool PLAIN>
+int launchp(const GemmParams& P, hipStream_t stream) {
+  const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
+  const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
+  dim3 grid((unsigned)nwg, 1, 1);
+  static unsigned long long lds_done = 0;   // per instantiation
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BKIND, CK, PLAIN>), GEMM_LDS_BYTES,
+                               &lds_done, "gemm_f32"))
+    return rc;
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKIND, CK, PLAIN>), grid, dim3(256), GEMM_LDS_BYTES, stream, P);
+  VTS_CHECK_LAUNCH("gemm_f32");
   return VTS_OK;
 }
 
 template <int AK, int BKIND, int CK>
 int launch(const GemmParams& P, hipStream_t stream) {
-  if (P.mode == 1) return launch3<AK, BKIND, CK>(P, stream);
-  const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
-  const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
-  dim3 grid((unsigned)nwg, 1, 1);
-  static unsigned long long lds_done = 0;   // per instantiation
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BKIND, CK>), GEMM_LDS_BYTES, &lds_done,
-                               "gemm_f32"))
-    return rc;
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKIND, CK>), grid, dim3(256), GEMM_LDS_BYTES, stream, P);
-  VTS_CHECK_LAUNCH("gemm_f32");
-  return VTS_OK;
+  if constexpr (CK == C_ROW) {
+    if (plain_epilogue(P))
+      return P.mode == 1 ? launch3p<AK, BKIND, CK, true>(P, stream) : launchp<AK, BKIND, CK, true>(P, stream);
+  }
+  return P.mode == 1 ? launch3p<AK, BKIND, CK, false>(P, stream) : launchp<AK, BKIND, CK, false>(P, stream);
 }
 
 }  // namespace
@@ -950,6 +997,14 @@ size_t vts_gemm_slab_bytes(int M, int N, int ksplit) {
 static int finish_split(GemmParams P, float* Cfinal, long ldc, int accumulate, hipStream_t stream) {
   if (P.ksplit <= 1) return VTS_OK;
   const long total = (long)P.M * P.N;
+  if (P.ksplit <= 32) {
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3(blocks), dim3(256), 0, stream, P.C, Cfinal, P.M, P.N, ldc,
+                       P.ksplit, accumulate);
+    VTS_CHECK_LAUNCH("reduce_few_slabs");
+    return VTS_OK;
+  }
   int blocks = (int)((total + 63) / 64);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(1024), 0, stream, P.C, Cfinal, P.M, P.N, ldc,
