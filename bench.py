@@ -15,6 +15,7 @@ WORLD_SIZE / MASTER_* are read from the environment.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -241,6 +242,9 @@ def bench_transformer(a, dev, world, rank, launched):
 
     for _ in range(a.warmup):
         trainer.step(x, y)
+    # a full collection now, so that the interpreter's next generation-2 pass (~30 ms over torch's
+    # heap, due once per few hundred steps) does not land inside a ten-step timed region
+    gc.collect()
     sync()
     L.timer.enabled = True
     L.timer.reset()
@@ -349,6 +353,9 @@ def main():
 
     for _ in range(a.warmup):
         trainer.step(x, y)
+    # a full collection now, so that the interpreter's next generation-2 pass (~30 ms over torch's
+    # heap, due once per few hundred steps) does not land inside a ten-step timed region
+    gc.collect()
     sync()
     L.timer.enabled = True
     L.timer.reset()
