@@ -141,11 +141,13 @@ int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, f
  * relu+dropout (VTS_ACT_RELU_DROPOUT, kept elements scaled by x_act_scale): dx then holds the gradient
  * w.r.t. that activation's INPUT, dx = x != 0 ? (dy . w) * scale : 0, applied in the GEMM epilogue.  This is
  * linear2 -> dropout(relu(linear1)) of the encoder layer's feed-forward block without a separate pass over
- * the [tokens, 2048] gradient.  x_act = VTS_ACT_NONE is vts_linear_bwd. */
+ * the [tokens, 2048] gradient.  dx_colsum ([K] or NULL) receives the column sums of dx, i.e. the bias gradient
+ * of the layer that produced x, accumulated in the same epilogue.  x_act = VTS_ACT_NONE, dx_colsum = NULL is
+ * vts_linear_bwd. */
 int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act, float keep_scale, const float* x,
                       int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate, float* dw,
-                      float* db, int param_accumulate, int x_act, float x_act_scale, void* workspace,
-                      size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
+                      float* db, int param_accumulate, int x_act, float x_act_scale, float* dx_colsum,
+                      void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
                       vts_stream_t stream);
 
 /* act = VTS_ACT_RELU_DROPOUT with the mask drawn by the library's counter hash instead of fed in:

@@ -59,6 +59,9 @@ struct GemmParams {
   const float* mask_src;  // [M][N] (row stride ld_mask) or null: result = mask_src != 0 ? result * mask_scale : 0,
   long ld_mask;           // i.e. the gradient of a relu(+dropout) whose OUTPUT is mask_src, applied to a data gradient
   float mask_scale;
+  float* colpart;         // or null: [2 * ceil(M/128)][N] column sums of the finished output, one row per
+                          // (128-row tile, upper/lower 64 rows): the bias gradient of whatever produced the
+                          // operand this output is the gradient of, without another pass over it
   float* aux;          // act 3: [M][N] 1.0 where pre-activation >= 1e-6 (gradient passes)
   int accumulate;      // C += result (ksplit == 1 only)
   int ksplit;          // >1: grid.z slabs of M*N floats at C
@@ -324,6 +327,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
     const int c4 = (lane & 15) * 4;
     const int col0 = n0 + wn * 64 + c4;
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!plain) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -388,19 +392,38 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
           }
           if (P.accumulate) v += *reinterpret_cast<const f32x4*>(Cbase + off);
           *reinterpret_cast<f32x4*>(Cbase + off) = v;
+          csum += v;
         } else if (vec_ok && col0 + 3 < P.N && P.act == 4) {
           // hashed dropout: element hashes, one vector store
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = finish(v[e], off + e, row, col0 + e);
           *reinterpret_cast<f32x4*>(Cbase + off) = v;
+          csum += v;
         } else {
           for (int e = 0; e < 4; ++e)
-            if (col0 + e < P.N) Cbase[off + e] = finish(v[e], off + e, row, col0 + e);
+            if (col0 + e < P.N) {
+              const float o = finish(v[e], off + e, row, col0 + e);
+              Cbase[off + e] = o;
+              csum[e] += o;
+            }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    }
+    if (P.colpart) {   // the four row groups of the wave hold the same columns
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        csum[e] += __shfl_xor(csum[e], 16);
+        csum[e] += __shfl_xor(csum[e], 32);
+      }
+      if (lane < 16) {
+        float* dst = P.colpart + ((long)(m0 / BM) * 2 + wm) * P.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col0 + e < P.N) dst[col0 + e] = csum[e];
+      }
     }
   }
 }
@@ -929,7 +952,7 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 }
 
 static bool plain_epilogue(const GemmParams& P) {
-  return !P.bias0 && !P.bias1 && P.act == 0 && !P.mask_src;
+  return !P.bias0 && !P.bias1 && P.act == 0 && !P.mask_src && !P.colpart;
 }
 
 template <int AK, int BKIND, int CK, bool PLAIN>
@@ -1086,11 +1109,12 @@ int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* b
 
 // dX[M][K] (+)= dY[M][N] . W[N][K]
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
-                       int accumulate, const float* mask_src, long ld_mask, float mask_scale, int mode,
-                       hipStream_t stream) {
+                       int accumulate, const float* mask_src, long ld_mask, float mask_scale, float* colpart,
+                       int mode, hipStream_t stream) {
   GemmParams P{};
   P.mode = mode;
   P.mask_src = mask_src; P.ld_mask = ld_mask; P.mask_scale = mask_scale;
+  P.colpart = colpart;
   P.A = dY; P.B = W; P.C = dX;
   P.M = M; P.N = K; P.K = N;
   P.lda = lddy; P.ldb = K; P.ldc = lddx;

@@ -18,8 +18,8 @@ int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* b
                         int N, int K, int act, const float* keep, float keep_scale, unsigned long long drop_seed,
                         unsigned drop_thresh, float* aux, int mode, hipStream_t stream);
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
-                       int accumulate, const float* mask_src, long ld_mask, float mask_scale, int mode,
-                       hipStream_t stream);
+                       int accumulate, const float* mask_src, long ld_mask, float mask_scale, float* colpart,
+                       int mode, hipStream_t stream);
 int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, float* dW, float* slabs, int ksplit,
                        int M, int N, int K, int accumulate, int mode, hipStream_t stream);
 int vts_attn_mha(int bwd, const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, long ldo,
@@ -310,6 +310,7 @@ struct LinWs {
   float* dpre;
   float* slabs;
   float* colpart;
+  float* dxpart;     // [2 * ceil(M/128)][K] column sums of dx per half row tile
   int ksplit;
   size_t total;
 };
@@ -322,6 +323,7 @@ static LinWs lin_ws_layout(void* base, int64_t M, int64_t N, int64_t K) {
   w.ksplit = vts_gemm_pick_ksplit((int)N, (int)K, M, 0);
   w.slabs = reinterpret_cast<float*>(p + off); off += round256(vts_gemm_slab_bytes((int)N, (int)K, w.ksplit));
   w.colpart = reinterpret_cast<float*>(p + off); off += round256((size_t)vts_ew_colsum_chunks((int)M) * N * sizeof(float));
+  w.dxpart = reinterpret_cast<float*>(p + off); off += round256((size_t)2 * ((M + 127) / 128) * K * sizeof(float));
   w.total = off;
   return w;
 }
@@ -330,8 +332,8 @@ size_t vts_linear_bwd_workspace_bytes(int64_t M, int64_t N, int64_t K) { return 
 
 int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act, float keep_scale, const float* x,
                       int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate, float* dw, float* db,
-                      int param_accumulate, int x_act, float x_act_scale, void* workspace, size_t workspace_bytes,
-                      int64_t M, int64_t N, int64_t K, int dtype_mode, vts_stream_t stream) {
+                      int param_accumulate, int x_act, float x_act_scale, float* dx_colsum, void* workspace,
+                      size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode, vts_stream_t stream) {
   VTS_MODE_CHECK(dtype_mode);
   VTS_REQUIRE(dy && x && w && workspace && M > 0 && N > 0 && K > 0, "linear_bwd: bad arguments");
   VTS_REQUIRE(act >= 0 && act <= 4, "linear_bwd: unknown activation %d", act);
@@ -340,6 +342,7 @@ int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act
   VTS_REQUIRE(x_act == VTS_ACT_NONE || x_act == VTS_ACT_RELU || x_act == VTS_ACT_RELU_DROPOUT,
               "linear_bwd: x_act must be none, relu or relu+dropout");
   VTS_REQUIRE(x_act == VTS_ACT_NONE || !dx_accumulate, "linear_bwd: x_act cannot be combined with dx_accumulate");
+  VTS_REQUIRE(!dx_colsum || (dx && !dx_accumulate), "linear_bwd: dx_colsum needs dx, not accumulated");
   const LinWs ws = lin_ws_layout(workspace, M, N, K);
   VTS_REQUIRE(workspace_bytes >= ws.total, "linear_bwd: workspace %zu B < required %zu B", workspace_bytes, ws.total);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -352,7 +355,10 @@ int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act
   if (dx) {
     const bool fuse = x_act != VTS_ACT_NONE;
     VTS_RC(vts_gemm_linear_dx(dpre, N, w, dx, lddx, (int)M, (int)N, (int)K, dx_accumulate, fuse ? x : nullptr, ldx,
-                              x_act == VTS_ACT_RELU_DROPOUT ? x_act_scale : 1.f, mode, st));
+                              x_act == VTS_ACT_RELU_DROPOUT ? x_act_scale : 1.f, dx_colsum ? ws.dxpart : nullptr, mode,
+                              st));
+    if (dx_colsum)
+      VTS_RC(vts_colsum_partials(ws.dxpart, dx_colsum, (int)(2 * ((M + 127) / 128)), (int)K, K, 0, st));
   }
   if (dw)
     VTS_RC(vts_gemm_linear_dw(dpre, N, x, ldx, dw, ws.slabs, ws.ksplit, (int)M, (int)N, (int)K, param_accumulate,
@@ -369,7 +375,7 @@ int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, f
                    int param_accumulate, void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K,
                    int dtype_mode, vts_stream_t stream) {
   return vts_linear_bwd_ex(dy, y, aux, act, keep_scale, x, ldx, w, dx, lddx, dx_accumulate, dw, db, param_accumulate,
-                           VTS_ACT_NONE, 1.f, workspace, workspace_bytes, M, N, K, dtype_mode, stream);
+                           VTS_ACT_NONE, 1.f, nullptr, workspace, workspace_bytes, M, N, K, dtype_mode, stream);
 }
 
 // ------------------------------------------------------------------------------------- LayerNorm

@@ -44,7 +44,7 @@ SIGNATURES = {
     "vts_linear_bwd": (_int, [_ptr, _ptr, _ptr, _int, _f32, _ptr, _i64, _ptr, _ptr, _i64, _int, _ptr, _ptr, _int,
                               _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_linear_bwd_ex": (_int, [_ptr, _ptr, _ptr, _int, _f32, _ptr, _i64, _ptr, _ptr, _i64, _int, _ptr, _ptr, _int,
-                                 _int, _f32, _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
+                                 _int, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_layernorm_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr]),
     "vts_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "vts_layernorm_bwd": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _ptr, _sz,

@@ -248,17 +248,19 @@ class _FeedForward(torch.autograd.Function):
         st = L.stream()
         dpre = torch.empty(M, Fh, device=dev, dtype=torch.float32)
         dw2, db2 = torch.empty_like(w2), torch.empty(N, device=dev, dtype=torch.float32)
+        db1 = torch.empty(Fh, device=dev, dtype=torch.float32)
         ws_bytes = lib.vts_linear_bwd_workspace_bytes(M, N, Fh)
         ws = L.workspace(ws_bytes, dev)
         L.check(L.timer.call(f"linear_bwd {M}x{N}x{Fh}", lib.vts_linear_bwd_ex, L.ptr(dy), None, None, L.ACT_NONE, 1.0,
                              L.ptr(h), Fh, L.ptr(w2), L.ptr(dpre), Fh, 0, L.ptr(dw2), L.ptr(db2), 0,
-                             L.ACT_RELU_DROPOUT, scale, L.wptr(ws), ws_bytes, M, N, Fh, _MODE, st), "vts_linear_bwd_ex")
+                             L.ACT_RELU_DROPOUT, scale, L.ptr(db1), L.wptr(ws), ws_bytes, M, N, Fh, _MODE, st),
+                "vts_linear_bwd_ex")
         dx = torch.empty(M, K, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dw1, db1 = torch.empty_like(w1), torch.empty(Fh, device=dev, dtype=torch.float32)
+        dw1 = torch.empty_like(w1)   # db1 = column sums of dpre came out of the epilogue above
         ws_bytes = lib.vts_linear_bwd_workspace_bytes(M, Fh, K)
         ws = L.workspace(ws_bytes, dev)
         L.check(L.timer.call(f"linear_bwd {M}x{Fh}x{K}", lib.vts_linear_bwd, L.ptr(dpre), None, None, L.ACT_NONE, 1.0,
-                             L.ptr(x), x.stride(0), L.ptr(w1), L.ptr(dx), K, 0, L.ptr(dw1), L.ptr(db1), 0,
+                             L.ptr(x), x.stride(0), L.ptr(w1), L.ptr(dx), K, 0, L.ptr(dw1), None, 0,
                              L.wptr(ws), ws_bytes, M, Fh, K, _MODE, st), "vts_linear_bwd")
         return dx, dw1, db1, dw2, db2, None, None, None
 
