@@ -269,10 +269,12 @@ def bench_transformer(a, dev, world, rank, launched):
         avg_ms = tot_ms / n
         kernels[name] = {"launches_per_step": n // a.steps, "avg_ms": round(avg_ms, 4),
                          "share_of_step": round(tot_ms / a.steps / ms_per_step, 4)}
-        if name.startswith("linear_"):
+        if name.startswith("linear_") or name.startswith("ffn_"):
             dims = name.split()[1].split("x")
             M, N, K = [int(v) for v in dims]
             mult = 2.0 if name.startswith("linear_fwd") or name.endswith("nodx") else 4.0
+            if name.startswith("ffn_"):     # two products forward, four backward
+                mult = 4.0 if name.startswith("ffn_fwd") else 8.0
             kernels[name]["tflops"] = round(mult * M * N * K / (avg_ms * 1e-3) / 1e12, 2)
     dom = max((k for k in kernels if "tflops" in kernels[k]), key=lambda k: summ[k][1])
     dom_tflops = kernels[dom]["tflops"]
@@ -280,7 +282,8 @@ def bench_transformer(a, dev, world, rank, launched):
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round((3 if split else 1) * dom_tflops, 2),
                 "peak": PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                 "algorithmic_tflops": dom_tflops,
-                "note": "dense product FLOPs of the entry point (2*M*N*K forward; data + weight gradient backward) / its "
+                "note": "dense product FLOPs of the entry point (2*M*N*K per product: linear fwd 1, bwd 2; feed-forward block "
+                        "fwd 2, bwd 4) / its "
                         "device time (HIP events on the launch stream)" +
                         ("; three bf16 matrix-core products are executed per fp32 product" if split else "")}
     roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)

@@ -137,19 +137,6 @@ int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, f
                    size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
                    vts_stream_t stream);
 
-/* vts_linear_bwd for a layer whose input x is itself the output of a fused relu (x_act = VTS_ACT_RELU) or
- * relu+dropout (VTS_ACT_RELU_DROPOUT, kept elements scaled by x_act_scale): dx then holds the gradient
- * w.r.t. that activation's INPUT, dx = x != 0 ? (dy . w) * scale : 0, applied in the GEMM epilogue.  This is
- * linear2 -> dropout(relu(linear1)) of the encoder layer's feed-forward block without a separate pass over
- * the [tokens, 2048] gradient.  dx_colsum ([K] or NULL) receives the column sums of dx, i.e. the bias gradient
- * of the layer that produced x, accumulated in the same epilogue.  x_act = VTS_ACT_NONE, dx_colsum = NULL is
- * vts_linear_bwd. */
-int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act, float keep_scale, const float* x,
-                      int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate, float* dw,
-                      float* db, int param_accumulate, int x_act, float x_act_scale, float* dx_colsum,
-                      void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode,
-                      vts_stream_t stream);
-
 /* act = VTS_ACT_RELU_DROPOUT with the mask drawn by the library's counter hash instead of fed in:
  * element (row, col) is kept iff hash(seed, row*N + col) >= drop_p * 2^32 and scaled by 1/(1-drop_p);
  * seed 0 or drop_p 0 = eval mode (plain relu).  Backward is vts_linear_bwd with VTS_ACT_RELU_DROPOUT and
@@ -257,6 +244,23 @@ int vts_mha_bwd(const float* dout, int64_t lddo, const float* q, int64_t ldq, co
                 int64_t ldkv, const float* out, int64_t ldo, const float* lse, const uint8_t* keep,
                 float drop_p, uint64_t seed, float* dq, int64_t lddq, float* dk, float* dv, int64_t lddkv,
                 int64_t B, int64_t T, int64_t Tq, int64_t nhead, int64_t dh, vts_stream_t stream);
+/* Feed-forward block of the layer, y = linear2(dropout(relu(linear1(x)))), x [M, d] (row stride ldx),
+ * w1 [F, d], w2 [d, F] (F = dim_feedforward, 2048 in the reference's layers).  The dropout mask: keep (float
+ * 0/1 [M, F]) if given, else the counter hash when seed != 0 (element index row*F + col), else none.
+ * fwd writes hidden [M, F] (needed by backward) and, when mask != NULL, one bit per hidden element that is
+ * non-zero (vts_ffn_mask_bytes(M, F) bytes; needs F % 64 == 0): backward then applies the relu/dropout
+ * derivative from 1/32 of the bytes.  bwd: drop_scale = 1/(1-drop_p) if a mask was applied, else 1;
+ * dx may be NULL.  linear2's data-gradient GEMM applies the activation derivative and accumulates db1 in
+ * its epilogue, so the [M, F] gradient is written once and read twice (dx, dw1). */
+size_t vts_ffn_mask_bytes(int64_t M, int64_t F);
+size_t vts_ffn_bwd_workspace_bytes(int64_t M, int64_t d, int64_t F);
+int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,
+                const float* keep, float drop_p, uint64_t seed, float* hidden, void* mask, float* y, int64_t M,
+                int64_t d, int64_t F, int dtype_mode, vts_stream_t stream);
+int vts_ffn_bwd(const float* dy, const float* x, int64_t ldx, const float* w1, const float* w2,
+                const float* hidden, const void* mask, float drop_scale, float* dx, int64_t lddx, float* dw1,
+                float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, int64_t M, int64_t d,
+                int64_t F, int dtype_mode, vts_stream_t stream);
 /* out = residual + dropout(x) (residual NULL = 0): x + dropout1(sa) and x + dropout2(ff) of the layer */
 int vts_dropout_add_fwd(const float* residual, const float* x, const uint8_t* keep, float drop_p, uint64_t seed,
                         float* out, int64_t n, vts_stream_t stream);

@@ -260,6 +260,37 @@ def test_large_linear_with_hashed_dropout(M, K, N, mode):
     assert l2_rel(bd.grad, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("M,d,F,how", [(300, 64, 128, "hash"), (300, 64, 100, "hash"), (77, 16, 192, "keep"),
+                                       (1000, 32, 2048, "eval"), (129, 64, 64, "hash")])
+def test_feed_forward_block(M, d, F, how):
+    """vts_ffn_fwd / vts_ffn_bwd against torch, with and without the packed mask (F % 64)."""
+    import vts
+    from vts import functional as Fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + d + F)
+    x = torch.randn(M, d, generator=g)
+    w1, b1 = torch.randn(F, d, generator=g) / math.sqrt(d), torch.randn(F, generator=g) * 0.1
+    w2, b2 = torch.randn(d, F, generator=g) / math.sqrt(F), torch.randn(d, generator=g) * 0.1
+    dy = torch.randn(M, d, generator=g)
+    p, seed, keep = 0.2, 0, None
+    if how == "hash":
+        seed = 99991 + M
+        keep = Fn.dropout_mask(seed, p, (M, F), dev).cpu().float()
+    elif how == "keep":
+        keep = (torch.rand(M, F, generator=g) >= p).float()
+    ref_in = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    hid = torch.relu(torch.nn.functional.linear(ref_in[0], ref_in[1], ref_in[2]))
+    if keep is not None:
+        hid = hid * keep.double() / (1 - p)
+    torch.nn.functional.linear(hid, ref_in[3], ref_in[4]).backward(dy.double())
+    dev_in = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = vts.functional.feed_forward(*dev_in, keep.to(dev) if how == "keep" else None, p, seed)
+    y.backward(dy.to(dev))
+    assert l2_rel(y, torch.nn.functional.linear(hid, ref_in[3], ref_in[4])) < 1e-5
+    for a, b, nm in zip(dev_in, ref_in, ["x", "w1", "b1", "w2", "b2"]):
+        assert l2_rel(a.grad, b.grad) < 2e-5, nm
+
+
 def test_large_batch_bf16x3_matches_oracle():
     """Enough windows that the layer's products run on the split-bf16 kernels."""
     import vts

@@ -59,6 +59,8 @@ struct GemmParams {
   const float* mask_src;  // [M][N] (row stride ld_mask) or null: result = mask_src != 0 ? result * mask_scale : 0,
   long ld_mask;           // i.e. the gradient of a relu(+dropout) whose OUTPUT is mask_src, applied to a data gradient
   float mask_scale;
+  const unsigned long long* mask_bits;   // the same mask as packed bits written by bits_out (N % 64 == 0)
+  unsigned long long* bits_out;          // or null: [M][N/64] words, bit set where the finished output is non-zero
   float* colpart;         // or null: [2 * ceil(M/128)][N] column sums of the finished output, one row per
                           // (128-row tile, upper/lower 64 rows): the bias gradient of whatever produced the
                           // operand this output is the gradient of, without another pass over it
@@ -315,26 +317,28 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
     // 16 lanes cover 256 contiguous bytes of a row, and bias, activation, dropout and the masks are
     // applied on that side with vector loads.  The k loop ended with a workgroup barrier, so the
     // operand tiles in LDS are dead.
-    float* Cbase = P.C + (P.ksplit > 1 ? (long)zslice * P.M * P.N : 0);
-    const long ldc = (P.ksplit > 1) ? P.N : P.ldc;
-    const bool plain = P.ksplit > 1;
+    // (split-K launches carry no bias, activation or mask and take the PLAIN variant above)
+    float* Cbase = P.C;
+    const long ldc = P.ldc;
     constexpr int SP = 68;
     float* patch = stage + (wm * 2 + wn) * (16 * SP);
     const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cbase) & 15) == 0) &&
                         (!P.keep || (reinterpret_cast<uintptr_t>(P.keep) & 15) == 0) &&
                         (!P.aux || (reinterpret_cast<uintptr_t>(P.aux) & 15) == 0) &&
                         (!P.mask_src || ((reinterpret_cast<uintptr_t>(P.mask_src) & 15) == 0 && (P.ld_mask & 3) == 0));
-    const int c4 = (lane & 15) * 4;
+    const int cg = lane & 15;             // column group: columns col0 .. col0+3
+    const int rq = lane >> 4;             // row within a group of four
+    const int c4 = cg * 4;
     const int col0 = n0 + wn * 64 + c4;
+    const long bitcol = (n0 + wn * 64) >> 6;   // 64-column block index of this wave (mask words)
+    const long bitld = P.N >> 6;
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!plain) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (col0 + e < P.N) {
-          if (P.bias0) bias4[e] += P.bias0[col0 + e];
-          if (P.bias1) bias4[e] += P.bias1[col0 + e];
-        }
+    for (int e = 0; e < 4; ++e) {
+      if (col0 + e < P.N) {
+        if (P.bias0) bias4[e] += P.bias0[col0 + e];
+        if (P.bias1) bias4[e] += P.bias1[col0 + e];
       }
     }
     auto finish = [&](float v, long off, int row, int col) -> float {   // off = row * ldc + col
@@ -364,48 +368,64 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int rl = it * 4 + (lane >> 4);
+        const int rl = it * 4 + rq;
         const int row = m0 + wm * 64 + i * 16 + rl;
         f32x4 v = *reinterpret_cast<const f32x4*>(patch + rl * SP + c4);
-        if (row >= P.M || col0 >= P.N) continue;
-        const long off = (long)row * ldc + col0;
-        if (plain) {
-          if (vec_ok && col0 + 3 < P.N) *reinterpret_cast<f32x4*>(Cbase + off) = v;
-          else
-            for (int e = 0; e < 4; ++e)
-              if (col0 + e < P.N) Cbase[off + e] = v[e];
-          continue;
-        }
-        v += bias4;
-        if (vec_ok && col0 + 3 < P.N && P.act != 3 && !(P.act == 4 && P.keep == nullptr && P.drop_thresh)) {
-          // vector forms of the element transforms (clamp-with-aux and hashed dropout take the scalar path below)
-          if (P.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-          else if (P.act == 2) { v[0] = expf(v[0]); v[1] = expf(v[1]); v[2] = expf(v[2]); v[3] = expf(v[3]); }
-          else if (P.act == 4) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            if (P.keep) v = v * *reinterpret_cast<const f32x4*>(P.keep + off) * P.keep_scale;
-          }
-          if (P.mask_src) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(P.mask_src + (long)row * P.ld_mask + col0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (mk[e] != 0.f) ? v[e] * P.mask_scale : 0.f;
-          }
-          if (P.accumulate) v += *reinterpret_cast<const f32x4*>(Cbase + off);
-          *reinterpret_cast<f32x4*>(Cbase + off) = v;
-          csum += v;
-        } else if (vec_ok && col0 + 3 < P.N && P.act == 4) {
-          // hashed dropout: element hashes, one vector store
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = finish(v[e], off + e, row, col0 + e);
-          *reinterpret_cast<f32x4*>(Cbase + off) = v;
-          csum += v;
-        } else {
-          for (int e = 0; e < 4; ++e)
-            if (col0 + e < P.N) {
-              const float o = finish(v[e], off + e, row, col0 + e);
-              Cbase[off + e] = o;
-              csum[e] += o;
+        const bool valid = row < P.M && col0 < P.N;
+        unsigned nz = 0;                  // bit e: element e of this lane is non-zero in the output
+        if (valid) {
+          const long off = (long)row * ldc + col0;
+          v += bias4;
+          if (vec_ok && col0 + 3 < P.N && P.act != 3 && !(P.act == 4 && P.keep == nullptr && P.drop_thresh)) {
+            // vector forms of the element transforms (clamp-with-aux and hashed dropout take the paths below)
+            if (P.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            else if (P.act == 2) { v[0] = expf(v[0]); v[1] = expf(v[1]); v[2] = expf(v[2]); v[3] = expf(v[3]); }
+            else if (P.act == 4) {
+              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+              if (P.keep) v = v * *reinterpret_cast<const f32x4*>(P.keep + off) * P.keep_scale;
             }
+            if (P.mask_bits) {
+              const unsigned long long word = P.mask_bits[(long)row * bitld + bitcol];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = ((word >> (16 * e + cg)) & 1ull) ? v[e] * P.mask_scale : 0.f;
+            } else if (P.mask_src) {
+              const f32x4 mk = *reinterpret_cast<const f32x4*>(P.mask_src + (long)row * P.ld_mask + col0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (mk[e] != 0.f) ? v[e] * P.mask_scale : 0.f;
+            }
+            if (P.accumulate) v += *reinterpret_cast<const f32x4*>(Cbase + off);
+            *reinterpret_cast<f32x4*>(Cbase + off) = v;
+            csum += v;
+          } else if (vec_ok && col0 + 3 < P.N && P.act == 4) {
+            // hashed dropout: element hashes, one vector store
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = finish(v[e], off + e, row, col0 + e);
+            *reinterpret_cast<f32x4*>(Cbase + off) = v;
+            csum += v;
+          } else {
+            for (int e = 0; e < 4; ++e) {
+              if (col0 + e < P.N) {
+                v[e] = finish(v[e], off + e, row, col0 + e);
+                Cbase[off + e] = v[e];
+                csum[e] += v[e];
+              } else {
+                v[e] = 0.f;
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) nz |= (v[e] != 0.f ? 1u : 0u) << e;
+        }
+        if (P.bits_out) {
+          // One 64-bit word per (row, 64-column block): bit 16*e + cg <-> column 4*cg + e of the block.
+          // Every lane of the wave reaches the ballots (the branch above has rejoined).
+          unsigned long long word = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned long long bal = __ballot((nz >> e) & 1u);
+            word |= ((bal >> (16 * rq)) & 0xffffull) << (16 * e);
+          }
+          if (cg == 0 && row < P.M && n0 + wn * 64 < P.N) P.bits_out[(long)row * bitld + bitcol] = word;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -952,7 +972,7 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 }
 
 static bool plain_epilogue(const GemmParams& P) {
-  return !P.bias0 && !P.bias1 && P.act == 0 && !P.mask_src && !P.colpart;
+  return !P.bias0 && !P.bias1 && P.act == 0 && !P.mask_src && !P.mask_bits && !P.bits_out && !P.colpart;
 }
 
 template <int AK, int BKIND, int CK, bool PLAIN>
@@ -984,6 +1004,10 @@ int launchp(const GemmParams& P, hipStream_t stream) {
 
 template <int AK, int BKIND, int CK>
 int launch(const GemmParams& P, hipStream_t stream) {
+  if (P.ksplit > 1 && !plain_epilogue(P)) {
+    vts_set_error("gemm: split-K launches cannot carry a bias, activation, mask or column sums");
+    return VTS_ERR_ARG;
+  }
   if constexpr (CK == C_ROW) {
     if (plain_epilogue(P))
       return P.mode == 1 ? launch3p<AK, BKIND, CK, true>(P, stream) : launchp<AK, BKIND, CK, true>(P, stream);
@@ -1095,9 +1119,11 @@ int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs,
 // Y[M][N] = act(X[M][K] . W[N][K]^T + bias)
 int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
                         int N, int K, int act, const float* keep, float keep_scale, unsigned long long drop_seed,
-                        unsigned drop_thresh, float* aux, int mode, hipStream_t stream) {
+                        unsigned drop_thresh, float* aux, unsigned long long* bits_out, int mode,
+                        hipStream_t stream) {
   GemmParams P{};
   P.mode = mode;
+  P.bits_out = bits_out;
   P.drop_seed = drop_seed; P.drop_thresh = drop_thresh;
   P.A = X; P.B = W; P.C = Y;
   P.M = M; P.N = N; P.K = K;
@@ -1109,11 +1135,11 @@ int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* b
 
 // dX[M][K] (+)= dY[M][N] . W[N][K]
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
-                       int accumulate, const float* mask_src, long ld_mask, float mask_scale, float* colpart,
-                       int mode, hipStream_t stream) {
+                       int accumulate, const float* mask_src, long ld_mask, const unsigned long long* mask_bits,
+                       float mask_scale, float* colpart, int mode, hipStream_t stream) {
   GemmParams P{};
   P.mode = mode;
-  P.mask_src = mask_src; P.ld_mask = ld_mask; P.mask_scale = mask_scale;
+  P.mask_src = mask_bits ? nullptr : mask_src; P.ld_mask = ld_mask; P.mask_bits = mask_bits; P.mask_scale = mask_scale;
   P.colpart = colpart;
   P.A = dY; P.B = W; P.C = dX;
   P.M = M; P.N = K; P.K = N;

@@ -16,12 +16,20 @@ int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs,
                        int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream);
 int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
                         int N, int K, int act, const float* keep, float keep_scale, unsigned long long drop_seed,
-                        unsigned drop_thresh, float* aux, int mode, hipStream_t stream);
+                        unsigned drop_thresh, float* aux, unsigned long long* bits_out, int mode,
+                        hipStream_t stream);
 int vts_gemm_linear_dx(const float* dY, long lddy, const float* W, float* dX, long lddx, int M, int N, int K,
-                       int accumulate, const float* mask_src, long ld_mask, float mask_scale, float* colpart,
-                       int mode, hipStream_t stream);
+                       int accumulate, const float* mask_src, long ld_mask, const unsigned long long* mask_bits,
+                       float mask_scale, float* colpart, int mode, hipStream_t stream);
 int vts_gemm_linear_dw(const float* dY, long lddy, const float* X, long ldx, float* dW, float* slabs, int ksplit,
                        int M, int N, int K, int accumulate, int mode, hipStream_t stream);
+bool vts_ffn_fused_supported(long M, long d, long F, long ldx, const void* x, const void* keep);
+int vts_ffn_fused_fwd(const float* x, long ldx, const float* w1, const float* b1, const float* w2, const float* b2,
+                      const float* keep, unsigned long long seed, unsigned thresh, float scale, float* hidden,
+                      unsigned long long* bits, float* y, int M, int F, hipStream_t st);
+int vts_ffn_fused_bwd_dx(const float* dy, const float* w1, const float* w2, float* w1t, float* w2t,
+                         const float* hidden, const unsigned long long* bits, float scale, float* dpre, float* dx,
+                         long lddx, float* colpart, int M, int F, hipStream_t st);
 int vts_attn_mha(int bwd, const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, long ldo,
                  float* lse, const unsigned char* keep, float drop_p, unsigned long long seed, const float* dout,
                  long lddo, float* dq, long lddq, float* dk, float* dv, long lddkv, int B, int T, int Tq, int nhead,
@@ -290,7 +298,7 @@ int vts_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bia
   VTS_REQUIRE(act >= 0 && act <= 4, "linear_fwd: unknown activation %d", act);
   VTS_REQUIRE(fits_int(M) && fits_int(N) && fits_int(K), "linear_fwd: dimension too large");
   return vts_gemm_linear_fwd(x, ldx, w, bias, y, N, (int)M, (int)N, (int)K, act, keep, keep_scale, 0ull, 0u, aux,
-                             linear_mode(dtype_mode, M, N, K), reinterpret_cast<hipStream_t>(stream));
+                             nullptr, linear_mode(dtype_mode, M, N, K), reinterpret_cast<hipStream_t>(stream));
 }
 
 int vts_linear_relu_dropout_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t M,
@@ -303,7 +311,7 @@ int vts_linear_relu_dropout_fwd(const float* x, int64_t ldx, const float* w, con
   const bool on = drop_p > 0.f && seed != 0;
   return vts_gemm_linear_fwd(x, ldx, w, bias, y, N, (int)M, (int)N, (int)K, VTS_ACT_RELU_DROPOUT, nullptr,
                              on ? 1.f / (1.f - drop_p) : 1.f, seed, on ? vts_drop_thresh(drop_p) : 0u, nullptr,
-                             linear_mode(dtype_mode, M, N, K), reinterpret_cast<hipStream_t>(stream));
+                             nullptr, linear_mode(dtype_mode, M, N, K), reinterpret_cast<hipStream_t>(stream));
 }
 
 struct LinWs {
@@ -330,7 +338,7 @@ static LinWs lin_ws_layout(void* base, int64_t M, int64_t N, int64_t K) {
 
 size_t vts_linear_bwd_workspace_bytes(int64_t M, int64_t N, int64_t K) { return lin_ws_layout(nullptr, M, N, K).total; }
 
-int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act, float keep_scale, const float* x,
+static int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act, float keep_scale, const float* x,
                       int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate, float* dw, float* db,
                       int param_accumulate, int x_act, float x_act_scale, float* dx_colsum, void* workspace,
                       size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype_mode, vts_stream_t stream) {
@@ -355,8 +363,8 @@ int vts_linear_bwd_ex(const float* dy, const float* y, const float* aux, int act
   if (dx) {
     const bool fuse = x_act != VTS_ACT_NONE;
     VTS_RC(vts_gemm_linear_dx(dpre, N, w, dx, lddx, (int)M, (int)N, (int)K, dx_accumulate, fuse ? x : nullptr, ldx,
-                              x_act == VTS_ACT_RELU_DROPOUT ? x_act_scale : 1.f, dx_colsum ? ws.dxpart : nullptr, mode,
-                              st));
+                              nullptr, x_act == VTS_ACT_RELU_DROPOUT ? x_act_scale : 1.f,
+                              dx_colsum ? ws.dxpart : nullptr, mode, st));
     if (dx_colsum)
       VTS_RC(vts_colsum_partials(ws.dxpart, dx_colsum, (int)(2 * ((M + 127) / 128)), (int)K, K, 0, st));
   }
@@ -510,6 +518,98 @@ int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const flo
               "elbo_recon_bwd: bad arguments");
   return vts_ew_elbo_recon_bwd(family, recon, y, state, grad_out, threshold, B, (int)fs, drecon, dklpart,
                                (int)nklpart, dpi, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------- feed-forward block
+struct FfnWs {
+  float* dpre;       // [M][F] gradient w.r.t. linear1's pre-activation
+  void* lin2;        // vts_linear_bwd workspace of linear2 (M, d, F)
+  void* lin1;        // ... of linear1 (M, F, d)
+  float* w1t;        // [d][F] and [F][d]: the weights transposed for the fused backward kernel
+  float* w2t;
+  size_t lin2_bytes, lin1_bytes, total;
+};
+
+static FfnWs ffn_ws_layout(void* base, int64_t M, int64_t d, int64_t F) {
+  FfnWs w{};
+  char* p = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  w.dpre = reinterpret_cast<float*>(p + off); off += round256((size_t)M * F * sizeof(float));
+  w.lin2_bytes = lin_ws_layout(nullptr, M, d, F).total;
+  w.lin2 = p + off; off += w.lin2_bytes;
+  w.lin1_bytes = lin_ws_layout(nullptr, M, F, d).total;
+  w.lin1 = p + off; off += w.lin1_bytes;
+  w.w1t = reinterpret_cast<float*>(p + off); off += round256((size_t)d * F * sizeof(float));
+  w.w2t = reinterpret_cast<float*>(p + off); off += round256((size_t)d * F * sizeof(float));
+  w.total = off;
+  return w;
+}
+
+size_t vts_ffn_mask_bytes(int64_t M, int64_t F) { return (F % 64 == 0) ? (size_t)M * (F / 64) * 8 : 0; }
+size_t vts_ffn_bwd_workspace_bytes(int64_t M, int64_t d, int64_t F) { return ffn_ws_layout(nullptr, M, d, F).total; }
+
+int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,
+                const float* keep, float drop_p, uint64_t seed, float* hidden, void* mask, float* y, int64_t M,
+                int64_t d, int64_t F, int dtype_mode, vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_REQUIRE(x && w1 && w2 && hidden && y && M > 0 && d > 0 && F > 0 && ldx >= d, "ffn_fwd: bad arguments");
+  VTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ffn_fwd: drop_p %g outside [0, 1)", (double)drop_p);
+  VTS_REQUIRE(fits_int(M) && fits_int(d) && fits_int(F), "ffn_fwd: dimension too large");
+  VTS_REQUIRE(!mask || (F % 64 == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0),
+              "ffn_fwd: the packed mask needs F %% 64 == 0 and 8-byte alignment");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool hashed = !keep && drop_p > 0.f && seed != 0;
+  const bool dropped = keep || hashed;
+  if (linear_mode(dtype_mode, M, F, d) == 1 && b1 && b2 && vts_ffn_fused_supported(M, d, F, ldx, x, keep))
+    return vts_ffn_fused_fwd(x, ldx, w1, b1, w2, b2, keep, seed, hashed ? vts_drop_thresh(drop_p) : 0u,
+                             dropped ? 1.f / (1.f - drop_p) : 1.f, hidden, reinterpret_cast<unsigned long long*>(mask),
+                             y, (int)M, (int)F, st);
+  VTS_RC(vts_gemm_linear_fwd(x, ldx, w1, b1, hidden, F, (int)M, (int)F, (int)d, VTS_ACT_RELU_DROPOUT, keep,
+                             dropped ? 1.f / (1.f - drop_p) : 1.f, seed, hashed ? vts_drop_thresh(drop_p) : 0u, nullptr,
+                             reinterpret_cast<unsigned long long*>(mask), linear_mode(dtype_mode, M, F, d), st));
+  return vts_gemm_linear_fwd(hidden, F, w2, b2, y, d, (int)M, (int)d, (int)F, VTS_ACT_NONE, nullptr, 1.f, 0ull, 0u,
+                             nullptr, nullptr, linear_mode(dtype_mode, M, d, F), st);
+}
+
+int vts_ffn_bwd(const float* dy, const float* x, int64_t ldx, const float* w1, const float* w2, const float* hidden,
+                const void* mask, float drop_scale, float* dx, int64_t lddx, float* dw1, float* db1, float* dw2,
+                float* db2, void* workspace, size_t workspace_bytes, int64_t M, int64_t d, int64_t F, int dtype_mode,
+                vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_REQUIRE(dy && x && w1 && w2 && hidden && dw1 && db1 && dw2 && db2 && workspace && M > 0 && d > 0 && F > 0,
+              "ffn_bwd: bad arguments");
+  VTS_REQUIRE(!mask || F % 64 == 0, "ffn_bwd: the packed mask needs F %% 64 == 0");
+  const FfnWs ws = ffn_ws_layout(workspace, M, d, F);
+  VTS_REQUIRE(workspace_bytes >= ws.total, "ffn_bwd: workspace %zu B < required %zu B", workspace_bytes, ws.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const LinWs l2 = lin_ws_layout(ws.lin2, M, d, F);
+  const LinWs l1 = lin_ws_layout(ws.lin1, M, F, d);
+  const int mode2 = linear_mode(dtype_mode, M, d, F), mode1 = linear_mode(dtype_mode, M, F, d);
+  if (mode2 == 1 && vts_ffn_fused_supported(M, d, F, d, dy, nullptr) && (!dx || (lddx % 4) == 0)) {
+    // one kernel: dpre = mask * (dy . W2) written once, dx = dpre . W1 from the same registers, db1 partials
+    float* dxbuf = dx ? dx : ws.dpre;   // dx not wanted: the tile is still produced, into scratch that is overwritten next
+    VTS_REQUIRE(dx != nullptr, "ffn_bwd: the fused path produces dx; pass a buffer");
+    VTS_RC(vts_ffn_fused_bwd_dx(dy, w1, w2, ws.w1t, ws.w2t, hidden, reinterpret_cast<const unsigned long long*>(mask),
+                                drop_scale, ws.dpre, dxbuf, lddx, l2.dxpart, (int)M, (int)F, st));
+    VTS_RC(vts_colsum_partials(l2.dxpart, db1, (int)((M + 127) / 128), (int)F, F, 0, st));
+    VTS_RC(vts_gemm_linear_dw(dy, d, hidden, F, dw2, l2.slabs, l2.ksplit, (int)M, (int)d, (int)F, 0, mode2, st));
+    VTS_RC(vts_ew_colsum_rows(dy, d, (int)M, (int)d, l2.colpart, st));
+    VTS_RC(vts_colsum_partials(l2.colpart, db2, vts_ew_colsum_chunks((int)M), (int)d, d, 0, st));
+    return vts_gemm_linear_dw(ws.dpre, F, x, ldx, dw1, l1.slabs, l1.ksplit, (int)M, (int)F, (int)d, 0, mode1, st);
+  }
+  // linear2: the data gradient lands as linear1's pre-activation gradient (relu and dropout derivative in the
+  // epilogue, from the packed mask or from hidden != 0) together with its column sums = db1
+  VTS_RC(vts_gemm_linear_dx(dy, d, w2, ws.dpre, F, (int)M, (int)d, (int)F, 0, hidden, F,
+                            reinterpret_cast<const unsigned long long*>(mask), drop_scale, l2.dxpart, mode2, st));
+  VTS_RC(vts_colsum_partials(l2.dxpart, db1, (int)(2 * ((M + 127) / 128)), (int)F, F, 0, st));
+  VTS_RC(vts_gemm_linear_dw(dy, d, hidden, F, dw2, l2.slabs, l2.ksplit, (int)M, (int)d, (int)F, 0, mode2, st));
+  VTS_RC(vts_ew_colsum_rows(dy, d, (int)M, (int)d, l2.colpart, st));
+  VTS_RC(vts_colsum_partials(l2.colpart, db2, vts_ew_colsum_chunks((int)M), (int)d, d, 0, st));
+  // linear1
+  if (dx)
+    VTS_RC(vts_gemm_linear_dx(ws.dpre, F, w1, dx, lddx, (int)M, (int)F, (int)d, 0, nullptr, 0, nullptr, 1.f, nullptr,
+                              mode1, st));
+  return vts_gemm_linear_dw(ws.dpre, F, x, ldx, dw1, l1.slabs, l1.ksplit, (int)M, (int)F, (int)d, 0, mode1, st);
 }
 
 // ------------------------------------------------------------------- transformer encoder pieces

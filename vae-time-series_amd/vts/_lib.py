@@ -43,8 +43,6 @@ SIGNATURES = {
     "vts_linear_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vts_linear_bwd": (_int, [_ptr, _ptr, _ptr, _int, _f32, _ptr, _i64, _ptr, _ptr, _i64, _int, _ptr, _ptr, _int,
                               _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
-    "vts_linear_bwd_ex": (_int, [_ptr, _ptr, _ptr, _int, _f32, _ptr, _i64, _ptr, _ptr, _i64, _int, _ptr, _ptr, _int,
-                                 _int, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_layernorm_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr]),
     "vts_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "vts_layernorm_bwd": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _ptr, _sz,
@@ -61,6 +59,12 @@ SIGNATURES = {
                                   _ptr]),
     "vts_elbo_recon_bwd": (_int, [_int, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr]),
     "vts_linear_relu_dropout_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _u64, _int, _ptr]),
+    "vts_ffn_mask_bytes": (_sz, [_i64, _i64]),
+    "vts_ffn_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_ffn_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _u64, _ptr, _ptr, _ptr, _i64, _i64, _i64,
+                           _int, _ptr]),
+    "vts_ffn_bwd": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr,
+                           _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_mha_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _u64, _i64, _i64, _i64, _i64,
                            _i64, _ptr]),
     "vts_mha_bwd": (_int, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _u64, _ptr, _i64,

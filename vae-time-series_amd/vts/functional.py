@@ -204,10 +204,9 @@ def linear(x, weight, bias=None, act: int = L.ACT_NONE, keep: Optional[torch.Ten
 
 
 class _FeedForward(torch.autograd.Function):
-    """linear2(dropout(relu(linear1(x)))) as one autograd node, so that backward can hand the hidden
-    gradient from linear2's data-gradient GEMM straight to linear1's gradients: the relu/dropout
-    derivative is applied in that GEMM's epilogue (the mask is 'hidden != 0') and the
-    [tokens, dim_feedforward] gradient is written once."""
+    """linear2(dropout(relu(linear1(x)))) as one autograd node over vts_ffn_fwd / vts_ffn_bwd: the hidden
+    gradient goes from linear2's data-gradient GEMM straight to linear1's gradients (activation derivative
+    and db1 in that GEMM's epilogue), so the [tokens, dim_feedforward] gradient is written once."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, keep, drop_p: float, seed: int):
@@ -221,47 +220,35 @@ class _FeedForward(torch.autograd.Function):
         w1, w2, b1, b2 = w1.contiguous(), w2.contiguous(), b1.contiguous(), b2.contiguous()
         h = torch.empty(M, Fh, device=x.device, dtype=torch.float32)
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-        scale = 1.0 / (1.0 - drop_p)
-        st = L.stream()
-        if keep is not None:
-            L.check(L.timer.call(f"linear_fwd {M}x{Fh}x{K}", lib.vts_linear_fwd, L.ptr(x), x.stride(0), L.ptr(w1),
-                                 L.ptr(b1), L.ptr(h), M, Fh, K, L.ACT_RELU_DROPOUT, L.ptr(keep.contiguous()), scale,
-                                 None, _MODE, st), "vts_linear_fwd")
-        else:
-            L.check(L.timer.call(f"linear_fwd {M}x{Fh}x{K}", lib.vts_linear_relu_dropout_fwd, L.ptr(x), x.stride(0),
-                                 L.ptr(w1), L.ptr(b1), L.ptr(h), M, Fh, K, drop_p, seed, _MODE, st),
-                    "vts_linear_relu_dropout_fwd")
-        L.check(L.timer.call(f"linear_fwd {M}x{N}x{Fh}", lib.vts_linear_fwd, L.ptr(h), Fh, L.ptr(w2), L.ptr(b2),
-                             L.ptr(y), M, N, Fh, L.ACT_NONE, None, 1.0, None, _MODE, st), "vts_linear_fwd")
-        dropped = keep is not None or bool(seed)
-        ctx.cfg = (M, K, Fh, N, scale if dropped else 1.0)
-        ctx.save_for_backward(x, w1, w2, h)
+        mask_bytes = lib.vts_ffn_mask_bytes(M, Fh)
+        mask = L.workspace(mask_bytes, x.device) if mask_bytes else None
+        keep = _c(keep)
+        L.check(L.timer.call(f"ffn_fwd {M}x{Fh}x{K}", lib.vts_ffn_fwd, L.ptr(x), x.stride(0), L.ptr(w1), L.ptr(b1),
+                             L.ptr(w2), L.ptr(b2), L.ptr(keep), drop_p, seed, L.ptr(h),
+                             None if mask is None else L.wptr(mask), L.ptr(y), M, K, Fh, _MODE, L.stream()),
+                "vts_ffn_fwd")
+        dropped = keep is not None or (bool(seed) and drop_p > 0)
+        ctx.cfg = (M, K, Fh, 1.0 / (1.0 - drop_p) if dropped else 1.0)
+        ctx.save_for_backward(x, w1, w2, h, mask)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.load()
-        x, w1, w2, h = ctx.saved_tensors
-        M, K, Fh, N, scale = ctx.cfg
+        x, w1, w2, h, mask = ctx.saved_tensors
+        M, K, Fh, scale = ctx.cfg
         dev = x.device
         dy = dy.contiguous()
-        st = L.stream()
-        dpre = torch.empty(M, Fh, device=dev, dtype=torch.float32)
-        dw2, db2 = torch.empty_like(w2), torch.empty(N, device=dev, dtype=torch.float32)
-        db1 = torch.empty(Fh, device=dev, dtype=torch.float32)
-        ws_bytes = lib.vts_linear_bwd_workspace_bytes(M, N, Fh)
-        ws = L.workspace(ws_bytes, dev)
-        L.check(L.timer.call(f"linear_bwd {M}x{N}x{Fh}", lib.vts_linear_bwd_ex, L.ptr(dy), None, None, L.ACT_NONE, 1.0,
-                             L.ptr(h), Fh, L.ptr(w2), L.ptr(dpre), Fh, 0, L.ptr(dw2), L.ptr(db2), 0,
-                             L.ACT_RELU_DROPOUT, scale, L.ptr(db1), L.wptr(ws), ws_bytes, M, N, Fh, _MODE, st),
-                "vts_linear_bwd_ex")
         dx = torch.empty(M, K, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dw1 = torch.empty_like(w1)   # db1 = column sums of dpre came out of the epilogue above
-        ws_bytes = lib.vts_linear_bwd_workspace_bytes(M, Fh, K)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        db1 = torch.empty(Fh, device=dev, dtype=torch.float32)
+        db2 = torch.empty(K, device=dev, dtype=torch.float32)
+        ws_bytes = lib.vts_ffn_bwd_workspace_bytes(M, K, Fh)
         ws = L.workspace(ws_bytes, dev)
-        L.check(L.timer.call(f"linear_bwd {M}x{Fh}x{K}", lib.vts_linear_bwd, L.ptr(dpre), None, None, L.ACT_NONE, 1.0,
-                             L.ptr(x), x.stride(0), L.ptr(w1), L.ptr(dx), K, 0, L.ptr(dw1), None, 0,
-                             L.wptr(ws), ws_bytes, M, Fh, K, _MODE, st), "vts_linear_bwd")
+        L.check(L.timer.call(f"ffn_bwd {M}x{Fh}x{K}", lib.vts_ffn_bwd, L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(w1),
+                             L.ptr(w2), L.ptr(h), None if mask is None else L.wptr(mask), scale, L.ptr(dx), K,
+                             L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.wptr(ws), ws_bytes, M, K, Fh, _MODE,
+                             L.stream()), "vts_ffn_bwd")
         return dx, dw1, db1, dw2, db2, None, None, None
 
 
