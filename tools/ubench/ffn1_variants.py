@@ -23,7 +23,7 @@ def timeit(name, f, iters=5):
     e.record(); torch.cuda.synchronize()
     print(f"{name:46s} {s.elapsed_time(e) / iters:8.3f} ms", flush=True)
 
-for mode in (1, 0):
+for mode in (1,):
     st = L.stream()
     tag = "bf16x3" if mode else "f32   "
     timeit(f"{tag} no bias, no act", lambda: lib.vts_linear_fwd(L.ptr(x), K, L.ptr(w), None, L.ptr(y), M, N, K, 0, None, 1.0, None, mode, st))
@@ -31,4 +31,6 @@ for mode in (1, 0):
     timeit(f"{tag} bias + relu", lambda: lib.vts_linear_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), M, N, K, 1, None, 1.0, None, mode, st))
     timeit(f"{tag} bias + relu + hashed dropout", lambda: lib.vts_linear_relu_dropout_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), M, N, K, 0.2, 12345, mode, st))
     timeit(f"{tag} ffn_fwd (both products, hashed, mask bits)", lambda: lib.vts_ffn_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(w2), L.ptr(b2), None, 0.2, 12345, L.ptr(y), L.wptr(mask), L.ptr(y2), M, K, N, mode, st))
+    timeit(f"{tag} ffn_fwd eval (no dropout), mask bits", lambda: lib.vts_ffn_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(w2), L.ptr(b2), None, 0.2, 0, L.ptr(y), L.wptr(mask), L.ptr(y2), M, K, N, mode, st))
+    timeit(f"{tag} ffn_fwd hashed, no mask bits", lambda: lib.vts_ffn_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(w2), L.ptr(b2), None, 0.2, 12345, L.ptr(y), None, L.ptr(y2), M, K, N, mode, st))
     timeit(f"{tag} second product alone [M,2048]x[2048,64]", lambda: lib.vts_linear_fwd(L.ptr(y), N, L.ptr(w2), L.ptr(b2), L.ptr(y2), M, K, N, 0, None, 1.0, None, mode, st))

@@ -33,7 +33,8 @@ constexpr int OFF_W1 = 0;                        // [2][2] W_PLANE  = 16 KiB   r
 constexpr int OFF_W2 = OFF_W1 + 4 * W_PLANE;     // [2][2] W_PLANE  = 16 KiB   rows = out,    k = hidden
 constexpr int OFF_S = OFF_W2 + 4 * W_PLANE;      // [2][2] S_PLANE  = 32 KiB   rows = token,  k = hidden (also stages x)
 constexpr int OFF_CS = OFF_S + 4 * S_PLANE;      // [8][64] floats  =  2 KiB   column sums per wave (backward)
-constexpr int LDS_BYTES = OFF_CS + 8 * 64 * 4;
+constexpr int OFF_B1 = OFF_CS + 8 * 64 * 4;      // [64] floats: the chunk's slice of b1 (forward)
+constexpr int LDS_BYTES = OFF_B1 + 64 * 4;
 
 struct FfnParams {
   const float* x;        // [M][ldx]   forward: layer input; backward: dy
@@ -76,8 +77,10 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, uint4& hi, 
   lo = uint4{l0.x, l0.y, l1.x, l1.y};
 }
 
-template <bool BWD>
-__global__ __launch_bounds__(512, 1) void ffn_b2b_kernel(const FfnParams P) {
+// DROP (forward): 0 no dropout, 1 float keep mask, 2 counter hash.  BITS: forward writes / backward reads
+// the packed mask (backward without it compares the saved hidden activations with 0).
+template <bool BWD, int DROP, bool BITS>
+__global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -118,13 +121,20 @@ __global__ __launch_bounds__(512, 1) void ffn_b2b_kernel(const FfnParams P) {
   // weight chunk staging: thread -> (row tid/8, 8 floats at k = 8*(tid%8)) of both matrices
   const int wrow = tid >> 3, wkq = tid & 7;
   f32x4 wa0, wa1, wb0, wb1;
+  float bias_next = 0.f;
+  // Everything a chunk reads from global memory is fetched here, one chunk ahead and before the
+  // previous chunk's stores are issued: vmcnt counts loads and stores together and retires in order,
+  // so a load issued after a store cannot be waited for without also waiting for that store's
+  // round trip to HBM.
   auto fetch = [&](int c) {
+    if (!BWD && tid < HC) bias_next = P.b1[c * HC + tid];
     const float* pa = P.wa + (long)(c * HC + wrow) * D + wkq * 8;
     const float* pb = P.wb + (long)wrow * P.F + c * HC + wkq * 8;
     wa0 = *reinterpret_cast<const f32x4*>(pa); wa1 = *reinterpret_cast<const f32x4*>(pa + 4);
     wb0 = *reinterpret_cast<const f32x4*>(pb); wb1 = *reinterpret_cast<const f32x4*>(pb + 4);
   };
   auto stash = [&]() {
+    if (!BWD && tid < HC) reinterpret_cast<float*>(lds + OFF_B1)[tid] = bias_next;
     uint4 hi, lo;
     const int off = sw_off(wrow, (wkq & 3) * 16);
     split8(wa0, wa1, hi, lo);
@@ -139,6 +149,10 @@ __global__ __launch_bounds__(512, 1) void ffn_b2b_kernel(const FfnParams P) {
   const int token = row0 + w * 16 + r;                 // this lane's token in product 1's result
   const bool tok_ok = token < P.M;
   float* cs = reinterpret_cast<float*>(lds + OFF_CS);
+  // mask words are read one chunk ahead (an HBM round trip is ~the length of a chunk)
+  const unsigned long long* bits_row = (BWD && BITS && tok_ok) ? P.bits_in + (long)token * nchunks : nullptr;
+  unsigned long long word_next = bits_row ? bits_row[0] : 0ull;
+  float* mid_row = P.mid + (long)token * P.F + 4 * g;          // + c*HC + hb*16 per element group
 
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();                                   // every wave is done with the previous chunk's weights (and x staging)
@@ -151,6 +165,8 @@ __global__ __launch_bounds__(512, 1) void ffn_b2b_kernel(const FfnParams P) {
     }
     __syncthreads();
     if (c + 1 < nchunks) fetch(c + 1);                 // in flight during this chunk's arithmetic
+    const unsigned long long word = word_next;
+    if (BWD && BITS && bits_row && c + 1 < nchunks) word_next = bits_row[c + 1];
 
     // ---- product 1, transposed: S^T[hidden 64][token 16 of this wave], contraction d = 64
     f32x4 acc1[4];
@@ -178,21 +194,21 @@ __global__ __launch_bounds__(512, 1) void ffn_b2b_kernel(const FfnParams P) {
       const int hcol = hb * 16 + 4 * g;
       f32x4 v = acc1[hb];
       if constexpr (!BWD) {
-        v += *reinterpret_cast<const f32x4*>(P.b1 + c * HC + hcol);
+        v += *reinterpret_cast<const f32x4*>(lds + OFF_B1 + hcol * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        if (P.keep) {
+        if constexpr (DROP == 1) {
           if (tok_ok) v = v * *reinterpret_cast<const f32x4*>(P.keep + mid_off + hcol) * P.scale;
-        } else if (P.thresh) {
+        } else if constexpr (DROP == 2) {
           const unsigned long long idx = (unsigned long long)mid_off + hcol;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = vts_hash32(P.seed, idx + e) >= P.thresh ? v[e] * P.scale : 0.f;
         }
       } else {
-        if (P.bits_in) {
-          const unsigned long long word = tok_ok ? P.bits_in[(long)token * nchunks + c] : 0ull;
+        if constexpr (BITS) {
+          const unsigned nib = (unsigned)(word >> (16 * g + 4 * hb)) & 15u;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ((word >> (16 * e + 4 * hb + g)) & 1ull) ? v[e] * P.scale : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] * P.scale : 0.f;
         } else {
           f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
           if (tok_ok) hv = *reinterpret_cast<const f32x4*>(P.hidden + mid_off + hcol);
@@ -201,9 +217,11 @@ __global__ __launch_bounds__(512, 1) void ffn_b2b_kernel(const FfnParams P) {
         }
       }
       if (!tok_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      else *reinterpret_cast<f32x4*>(P.mid + mid_off + hcol) = v;
+      else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mid_row + c * HC + hb * 16));   // streamed: not read again by this kernel
+      if constexpr (!BWD && BITS) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) nzbits |= (v[e] != 0.f ? 1u : 0u) << (4 * hb + e);
+        for (int e = 0; e < 4; ++e) nzbits |= (v[e] != 0.f ? 1u : 0u) << (4 * hb + e);
+      }
       colv[hb] = v;
       // second product's A operand: token row, k = hidden (hb>>1 picks the 32-wide k step)
       uint2 hi, lo;
@@ -213,18 +231,14 @@ __global__ __launch_bounds__(512, 1) void ffn_b2b_kernel(const FfnParams P) {
       *reinterpret_cast<uint2*>(lds + OFF_S + (hb >> 1) * 2 * S_PLANE + S_PLANE + off) = lo;
     }
     if constexpr (!BWD) {
-      if (P.bits_out) {
-        // word layout of the GEMM epilogues: bit 16*e + cg <-> hidden unit 4*cg + e of the 64-unit block
-        unsigned long long word = 0;
-#pragma unroll
-        for (int hb = 0; hb < 4; ++hb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            word |= (unsigned long long)((nzbits >> (4 * hb + e)) & 1u) << (16 * e + 4 * hb + g);
-        unsigned lo32 = (unsigned)word, hi32 = (unsigned)(word >> 32);
-        lo32 |= __shfl_xor(lo32, 16); hi32 |= __shfl_xor(hi32, 16);
-        lo32 |= __shfl_xor(lo32, 32); hi32 |= __shfl_xor(hi32, 32);
-        if (g == 0 && tok_ok) P.bits_out[(long)token * nchunks + c] = ((unsigned long long)hi32 << 32) | lo32;
+      if constexpr (BITS) {
+        // mask word of (token, 64-unit block): 16-bit field g holds this lane's bits, bit 4*hb + e <-> unit
+        // hb*16 + 4*g + e.  The four lanes of a token (g = 0..3) sit 16 lanes apart.
+        const unsigned pair = nzbits | (__shfl_xor(nzbits, 16) << 16);   // lane g=0: fields 0,1; lane g=2: fields 2,3
+        const unsigned other = __shfl_xor(pair, 32);
+        if (g == 0 && tok_ok) {
+          P.bits_out[(long)token * nchunks + c] = ((unsigned long long)other << 32) | pair;
+        }
       }
     } else {
       // column sums over this wave's 16 tokens; lanes r == 0 publish 4 hidden units per block
@@ -294,11 +308,12 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
   }
 }
 
-template <bool BWD>
+template <bool BWD, int DROP, bool BITS>
 int launch_b2b(const FfnParams& P, hipStream_t st) {
   static unsigned long long done = 0;
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_b2b_kernel<BWD>), LDS_BYTES, &done, "ffn_b2b")) return rc;
-  hipLaunchKernelGGL(ffn_b2b_kernel<BWD>, dim3((unsigned)((P.M + TOK - 1) / TOK)), dim3(512), LDS_BYTES, st, P);
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_b2b_kernel<BWD, DROP, BITS>), LDS_BYTES, &done, "ffn_b2b"))
+    return rc;
+  hipLaunchKernelGGL((ffn_b2b_kernel<BWD, DROP, BITS>), dim3((unsigned)((P.M + TOK - 1) / TOK)), dim3(512), LDS_BYTES, st, P);
   VTS_CHECK_LAUNCH("ffn_b2b");
   return VTS_OK;
 }
@@ -316,7 +331,15 @@ int vts_ffn_fused_fwd(const float* x, long ldx, const float* w1, const float* b1
   P.x = x; P.ldx = ldx; P.wa = w1; P.wb = w2; P.b1 = b1; P.b2 = b2;
   P.keep = keep; P.seed = seed; P.thresh = thresh; P.scale = scale;
   P.mid = hidden; P.bits_out = bits; P.out = y; P.ldo = D; P.M = M; P.F = F;
-  return launch_b2b<false>(P, st);
+  const int drop = keep ? 1 : (thresh ? 2 : 0);
+  if (bits) {
+    if (drop == 2) return launch_b2b<false, 2, true>(P, st);
+    if (drop == 1) return launch_b2b<false, 1, true>(P, st);
+    return launch_b2b<false, 0, true>(P, st);
+  }
+  if (drop == 2) return launch_b2b<false, 2, false>(P, st);
+  if (drop == 1) return launch_b2b<false, 1, false>(P, st);
+  return launch_b2b<false, 0, false>(P, st);
 }
 
 // w2t [F][64] and w1t [64][F] are scratch for the transposed weights; colpart [ceil(M/128)][F].
@@ -331,5 +354,5 @@ int vts_ffn_fused_bwd_dx(const float* dy, const float* w1, const float* w2, floa
   P.x = dy; P.ldx = D; P.wa = w2t; P.wb = w1t;
   P.scale = scale; P.mid = dpre; P.hidden = hidden; P.bits_in = bits;
   P.out = dx; P.ldo = lddx; P.colpart = colpart; P.M = M; P.F = F;
-  return launch_b2b<true>(P, st);
+  return bits ? launch_b2b<true, 0, true>(P, st) : launch_b2b<true, 0, false>(P, st);
 }

@@ -386,8 +386,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
             }
             if (P.mask_bits) {
               const unsigned long long word = P.mask_bits[(long)row * bitld + bitcol];
+              const unsigned nib = (unsigned)(word >> (16 * (cg & 3) + 4 * (cg >> 2))) & 15u;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = ((word >> (16 * e + cg)) & 1ull) ? v[e] * P.mask_scale : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] * P.mask_scale : 0.f;
             } else if (P.mask_src) {
               const f32x4 mk = *reinterpret_cast<const f32x4*>(P.mask_src + (long)row * P.ld_mask + col0);
 #pragma unroll
@@ -417,15 +418,16 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
           for (int e = 0; e < 4; ++e) nz |= (v[e] != 0.f ? 1u : 0u) << e;
         }
         if (P.bits_out) {
-          // One 64-bit word per (row, 64-column block): bit 16*e + cg <-> column 4*cg + e of the block.
-          // Every lane of the wave reaches the ballots (the branch above has rejoined).
-          unsigned long long word = 0;
+          // One 64-bit word per (row, 64-column block).  Column c of the block sits at bit
+          // 16*((c>>2)&3) + 4*(c>>4) + (c&3): this lane's four columns are one nibble, and the 16 lanes of
+          // the row are OR-ed together with xor-shuffles (every lane of the wave reaches them: the branch
+          // above has rejoined).  The fused feed-forward kernels use the same layout.
+          const int sh = 16 * (cg & 3) + 4 * (cg >> 2);
+          unsigned lo32 = sh < 32 ? nz << sh : 0u, hi32 = sh >= 32 ? nz << (sh - 32) : 0u;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned long long bal = __ballot((nz >> e) & 1u);
-            word |= ((bal >> (16 * rq)) & 0xffffull) << (16 * e);
-          }
-          if (cg == 0 && row < P.M && n0 + wn * 64 < P.N) P.bits_out[(long)row * bitld + bitcol] = word;
+          for (int o = 1; o < 16; o <<= 1) { lo32 |= __shfl_xor(lo32, o); hi32 |= __shfl_xor(hi32, o); }
+          if (cg == 0 && row < P.M && n0 + wn * 64 < P.N)
+            P.bits_out[(long)row * bitld + bitcol] = ((unsigned long long)hi32 << 32) | lo32;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
