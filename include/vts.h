@@ -247,11 +247,13 @@ int vts_mha_bwd(const float* dout, int64_t lddo, const float* q, int64_t ldq, co
 /* Feed-forward block of the layer, y = linear2(dropout(relu(linear1(x)))), x [M, d] (row stride ldx),
  * w1 [F, d], w2 [d, F] (F = dim_feedforward, 2048 in the reference's layers).  The dropout mask: keep (float
  * 0/1 [M, F]) if given, else the counter hash when seed != 0 (element index row*F + col), else none.
- * fwd writes hidden [M, F] (needed by backward) and, when mask != NULL, one bit per hidden element that is
+ * fwd writes hidden [M, F] (needed by backward; the buffer must hold vts_ffn_hidden_bytes(M, F), rows padded to
+ * a multiple of 128 that the kernels may scribble on) and, when mask != NULL, one bit per hidden element that is
  * non-zero (vts_ffn_mask_bytes(M, F) bytes; needs F % 64 == 0): backward then applies the relu/dropout
  * derivative from 1/32 of the bytes.  bwd: drop_scale = 1/(1-drop_p) if a mask was applied, else 1;
  * dx may be NULL.  linear2's data-gradient GEMM applies the activation derivative and accumulates db1 in
  * its epilogue, so the [M, F] gradient is written once and read twice (dx, dw1). */
+size_t vts_ffn_hidden_bytes(int64_t M, int64_t F);
 size_t vts_ffn_mask_bytes(int64_t M, int64_t F);
 size_t vts_ffn_bwd_workspace_bytes(int64_t M, int64_t d, int64_t F);
 int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -32,8 +32,8 @@ constexpr int S_PLANE = TOK * ROWB;              // 8 KiB: 128 token rows
 constexpr int OFF_W1 = 0;                        // [2][2] W_PLANE  = 16 KiB   rows = hidden, k = d
 constexpr int OFF_W2 = OFF_W1 + 4 * W_PLANE;     // [2][2] W_PLANE  = 16 KiB   rows = out,    k = hidden
 constexpr int OFF_S = OFF_W2 + 4 * W_PLANE;      // [2][2] S_PLANE  = 32 KiB   rows = token,  k = hidden (also stages x)
-constexpr int OFF_CS = OFF_S + 4 * S_PLANE;      // [8][64] floats  =  2 KiB   column sums per wave (backward)
-constexpr int OFF_B1 = OFF_CS + 8 * 64 * 4;      // [64] floats: the chunk's slice of b1 (forward)
+constexpr int OFF_CS = OFF_S + 4 * S_PLANE;      // [2][8][64] floats = 4 KiB  column sums per wave, two chunks in flight (backward)
+constexpr int OFF_B1 = OFF_CS + 2 * 8 * 64 * 4;  // [64] floats: the chunk's slice of b1 (forward)
 constexpr int LDS_BYTES = OFF_B1 + 64 * 4;
 
 struct FfnParams {
@@ -122,12 +122,9 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
   const int wrow = tid >> 3, wkq = tid & 7;
   f32x4 wa0, wa1, wb0, wb1;
   float bias_next = 0.f;
-  // Everything a chunk reads from global memory is fetched here, one chunk ahead and before the
-  // previous chunk's stores are issued: vmcnt counts loads and stores together and retires in order,
-  // so a load issued after a store cannot be waited for without also waiting for that store's
-  // round trip to HBM.
+  // everything a chunk reads from global memory, fetched one chunk ahead
   auto fetch = [&](int c) {
-    if (!BWD && tid < HC) bias_next = P.b1[c * HC + tid];
+    if constexpr (!BWD) bias_next = P.b1[c * HC + (tid & (HC - 1))];
     const float* pa = P.wa + (long)(c * HC + wrow) * D + wkq * 8;
     const float* pb = P.wb + (long)wrow * P.F + c * HC + wkq * 8;
     wa0 = *reinterpret_cast<const f32x4*>(pa); wa1 = *reinterpret_cast<const f32x4*>(pa + 4);
@@ -150,23 +147,30 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
   const bool tok_ok = token < P.M;
   float* cs = reinterpret_cast<float*>(lds + OFF_CS);
   // mask words are read one chunk ahead (an HBM round trip is ~the length of a chunk)
-  const unsigned long long* bits_row = (BWD && BITS && tok_ok) ? P.bits_in + (long)token * nchunks : nullptr;
+  const unsigned long long* bits_row = (BWD && BITS) ? P.bits_in + (long)token * nchunks : nullptr;   // rows are padded to 128
   unsigned long long word_next = bits_row ? bits_row[0] : 0ull;
   float* mid_row = P.mid + (long)token * P.F + 4 * g;          // + c*HC + hb*16 per element group
+  stash();                                             // chunk 0 (the x fragments were read before the barrier above)
+  __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();                                   // every wave is done with the previous chunk's weights (and x staging)
-    stash();
+    // Next chunk's global reads, in flight during this chunk's arithmetic and waited for at the bottom of
+    // the iteration.  The loop body has no data-dependent branch around a global load or store (the last chunk
+    // re-fetches itself, rows past M land in the padding rows of the [tokens, F] buffers) and every load of
+    // an iteration is issued before its stores: vmcnt counts loads and stores together and retires in order,
+    // so the wait for these loads can leave exactly this iteration's stores outstanding instead of draining
+    // them (an HBM round trip per chunk otherwise).
+    const int cn = c + 1 < nchunks ? c + 1 : c;
+    fetch(cn);
+    const unsigned long long word = word_next;
+    if constexpr (BWD && BITS) word_next = bits_row[cn];
     if (BWD && c > 0 && w == 0) {                      // column sums of the previous chunk: fold the 8 waves
+      const float* prev = cs + ((c - 1) & 1) * 512;
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += cs[q * 64 + lane];
+      for (int q = 0; q < 8; ++q) s += prev[q * 64 + lane];
       P.colpart[(long)blockIdx.x * P.F + (c - 1) * HC + lane] = s;
     }
-    __syncthreads();
-    if (c + 1 < nchunks) fetch(c + 1);                 // in flight during this chunk's arithmetic
-    const unsigned long long word = word_next;
-    if (BWD && BITS && bits_row && c + 1 < nchunks) word_next = bits_row[c + 1];
 
     // ---- product 1, transposed: S^T[hidden 64][token 16 of this wave], contraction d = 64
     f32x4 acc1[4];
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
         }
       }
       if (!tok_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mid_row + c * HC + hb * 16));   // streamed: not read again by this kernel
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mid_row + c * HC + hb * 16));   // streamed: not read again by this kernel
       if constexpr (!BWD && BITS) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) nzbits |= (v[e] != 0.f ? 1u : 0u) << (4 * hb + e);
@@ -234,11 +238,12 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
       if constexpr (BITS) {
         // mask word of (token, 64-unit block): 16-bit field g holds this lane's bits, bit 4*hb + e <-> unit
         // hb*16 + 4*g + e.  The four lanes of a token (g = 0..3) sit 16 lanes apart.
-        const unsigned pair = nzbits | (__shfl_xor(nzbits, 16) << 16);   // lane g=0: fields 0,1; lane g=2: fields 2,3
+        // All four lanes of the token assemble and store the same word (an unconditional store, see above).
+        const unsigned partner = __shfl_xor(nzbits, 16);
+        const unsigned pair = (g & 1) ? (partner | (nzbits << 16)) : (nzbits | (partner << 16));   // fields (0,1) or (2,3)
         const unsigned other = __shfl_xor(pair, 32);
-        if (g == 0 && tok_ok) {
-          P.bits_out[(long)token * nchunks + c] = ((unsigned long long)other << 32) | pair;
-        }
+        const unsigned long long full = (g & 2) ? (((unsigned long long)pair << 32) | other) : (((unsigned long long)other << 32) | pair);
+        P.bits_out[(long)token * nchunks + c] = full;
       }
     } else {
       // column sums over this wave's 16 tokens; lanes r == 0 publish 4 hidden units per block
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
         for (int e = 0; e < 4; ++e) {
           float s = colv[hb][e];
           s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-          if (r == 0) cs[w * 64 + hb * 16 + 4 * g + e] = s;
+          if (r == 0) cs[(c & 1) * 512 + w * 64 + hb * 16 + 4 * g + e] = s;
         }
     }
     wave_lds_sync();                                   // S rows of this wave are written and read by this wave only
@@ -269,14 +274,16 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
         acc2[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, bh, acc2[ob], 0, 0, 0);
       }
     }
-    wave_lds_sync();                                   // before this wave overwrites its S rows in the next chunk
+    __syncthreads();                                   // every wave is done with this chunk's weights (and its S rows)
+    stash();                                           // next chunk's weights: waits for the fetch above only
+    __syncthreads();
   }
   if constexpr (BWD) {
-    __syncthreads();
     if (w == 0) {
+      const float* prev = cs + ((nchunks - 1) & 1) * 512;
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += cs[q * 64 + lane];
+      for (int q = 0; q < 8; ++q) s += prev[q * 64 + lane];
       P.colpart[(long)blockIdx.x * P.F + (nchunks - 1) * HC + lane] = s;
     }
   }

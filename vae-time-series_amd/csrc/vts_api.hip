@@ -521,6 +521,10 @@ int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const flo
 }
 
 // ------------------------------------------------------------------------- feed-forward block
+// The fused kernels work on whole 128-token tiles and store without bounds branches: the [tokens, F] buffers
+// they write (hidden, mask, and dpre inside the workspace) carry rows up to the next multiple of 128.
+static int64_t ffn_rows(int64_t M) { return (M + 127) / 128 * 128; }
+
 struct FfnWs {
   float* dpre;       // [M][F] gradient w.r.t. linear1's pre-activation
   void* lin2;        // vts_linear_bwd workspace of linear2 (M, d, F)
@@ -534,7 +538,7 @@ static FfnWs ffn_ws_layout(void* base, int64_t M, int64_t d, int64_t F) {
   FfnWs w{};
   char* p = reinterpret_cast<char*>(base);
   size_t off = 0;
-  w.dpre = reinterpret_cast<float*>(p + off); off += round256((size_t)M * F * sizeof(float));
+  w.dpre = reinterpret_cast<float*>(p + off); off += round256((size_t)ffn_rows(M) * F * sizeof(float));
   w.lin2_bytes = lin_ws_layout(nullptr, M, d, F).total;
   w.lin2 = p + off; off += w.lin2_bytes;
   w.lin1_bytes = lin_ws_layout(nullptr, M, F, d).total;
@@ -545,7 +549,8 @@ static FfnWs ffn_ws_layout(void* base, int64_t M, int64_t d, int64_t F) {
   return w;
 }
 
-size_t vts_ffn_mask_bytes(int64_t M, int64_t F) { return (F % 64 == 0) ? (size_t)M * (F / 64) * 8 : 0; }
+size_t vts_ffn_hidden_bytes(int64_t M, int64_t F) { return (size_t)ffn_rows(M) * F * sizeof(float); }
+size_t vts_ffn_mask_bytes(int64_t M, int64_t F) { return (F % 64 == 0) ? (size_t)ffn_rows(M) * (F / 64) * 8 : 0; }
 size_t vts_ffn_bwd_workspace_bytes(int64_t M, int64_t d, int64_t F) { return ffn_ws_layout(nullptr, M, d, F).total; }
 
 int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,

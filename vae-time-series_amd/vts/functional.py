@@ -218,7 +218,8 @@ class _FeedForward(torch.autograd.Function):
         Fh = w1.shape[0]
         N = w2.shape[0]
         w1, w2, b1, b2 = w1.contiguous(), w2.contiguous(), b1.contiguous(), b2.contiguous()
-        h = torch.empty(M, Fh, device=x.device, dtype=torch.float32)
+        # rows padded to the kernels' 128-token tiles; only the first M are meaningful
+        h = torch.empty(lib.vts_ffn_hidden_bytes(M, Fh) // 4, device=x.device, dtype=torch.float32)[:M * Fh].view(M, Fh)
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         mask_bytes = lib.vts_ffn_mask_bytes(M, Fh)
         mask = L.workspace(mask_bytes, x.device) if mask_bytes else None
