@@ -69,6 +69,7 @@ struct GemmParams {
   int ksplit;          // >1: grid.z slabs of M*N floats at C
   int kchunk;          // K elements per split (multiple of 32)
   int mode;            // 0 = f32 MFMA, 1 = bf16x3 split on the bf16 MFMA
+  int big_split;       // split-K plan made for the 256 x 128 tile kernel
 };
 
 __device__ __forceinline__ long window_row(int m, int T, int Bwin, int tshift, bool& valid) {
@@ -236,10 +237,11 @@ __device__ __forceinline__ void store_b(float* __restrict__ Bs, int tid, const f
 // (and its L2): all tiles that read the same operand panel - the n tiles of one m tile, or
 // every tile of one k slice - are given ids equal mod 8 and adjacent in time, so the panel is
 // fetched into one L2 once instead of into all eight.  Returns false for padding workgroups.
+template <int TBM = 128>
 __device__ __forceinline__ bool map_workgroup(const GemmParams& P, int& m0, int& n0, int& zslice, int& kbeg,
                                               int& kend) {
   const int tiles_n = (P.N + BN - 1) / BN;
-  const int tiles_m = (P.M + BM - 1) / BM;
+  const int tiles_m = (P.M + TBM - 1) / TBM;
   int tile;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   if (P.ksplit > 1) {
@@ -253,7 +255,7 @@ __device__ __forceinline__ bool map_workgroup(const GemmParams& P, int& m0, int&
     tile = mt * tiles_n + j % tiles_n;
     zslice = 0;
   }
-  m0 = (tile / tiles_n) * BM;
+  m0 = (tile / tiles_n) * TBM;
   n0 = (tile % tiles_n) * BN;
   kbeg = zslice * P.kchunk;
   kend = min(P.K, kbeg + P.kchunk);
@@ -925,6 +927,125 @@ __global__ __launch_bounds__(256, VTS_GEMM3_WPS) void gemm_bf16x3_kernel(const G
   epilogue<CK, PLAIN>(P, acc, m0, n0, zslice, wm, wn, lane, reinterpret_cast<float*>(lds3));
 }
 
+// ---- 256 x 128 tile variant ---------------------------------------------------------------------
+// The 128 x 128 kernel above runs at the rate one CU can pull operand bytes through its L1 (fp32
+// operands: 32 KiB per 32-deep k-step and workgroup), not at the matrix-core rate.  A 256 x 128
+// tile needs 48 KiB for twice the products, i.e. 25 % fewer bytes per FLOP.  8 waves: the two
+// halves of the workgroup (threads 0-255 / 256-511) each stage their own 128 rows of A with the
+// 256-thread lane maps above; the B tile of k-step j is staged by half j & 1, so a thread issues
+// four A loads every step and four B loads every other step.  One workgroup per CU (two waves per
+// SIMD, 96 KiB of LDS): two LDS stages and two register sets, loads two k-steps ahead of their
+// use, conversion and LDS stores in the shadow of the MFMAs, one LDS-only barrier per step.
+constexpr int BMB = 256;
+constexpr int STAGE_B = 2 * 2 * PLANE + 2 * PLANE;        // A hi, A lo (256 rows each), B hi, B lo
+constexpr size_t GEMM3B_LDS_BYTES = 2ul * STAGE_B;
+static_assert(GEMM3B_LDS_BYTES >= 8 * 16 * 68 * sizeof(float), "row-major epilogue stages 8 x [16][68] floats in LDS");
+
+template <int AK, int BKIND, int CK, bool PLAIN>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_big_kernel(const GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) char lds3[];   // [stage][A hi | A lo | B hi | B lo]
+  constexpr int OA = OpKindA<AK>::v, OB = OpKindB<BKIND>::v;
+  const int tid = threadIdx.x;
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int t2 = tid & 255;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;          // wave tile (wm, wn) of the 4 x 2 grid of 64 x 64 blocks
+  const int r = lane & 15, g = lane >> 4;
+
+  int m0, n0, zslice, kbeg, kend;
+  if (!map_workgroup<BMB>(P, m0, n0, zslice, kbeg, kend)) return;
+  const int ma = m0 + half * 128;                    // first A row this half stages
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float va[2][4][4], vb[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vb[i][0] = vb[i][1] = vb[i][2] = vb[i][3] = 0.f;
+  Stream3<OA> sa;
+  Stream3<OB> sb;
+  sa.init(P, true, ma, kbeg, t2);
+  sb.init(P, false, n0, kbeg + half * BK3, t2);     // this half's B tiles: k-steps half, half + 2, ...
+  auto load_a = [&](int j, float (&ra)[4][4]) {
+    const int k0 = kbeg + j * BK3;
+    if (k0 + BK3 <= kend && !sa.ragged()) sa.load_full(ra);
+    else load3<OA>(P, true, sa.rows, ma, k0, kend, t2, ra);
+    sa.advance();
+  };
+  auto load_b = [&](int j) {                         // j & 1 == half
+    const int k0 = kbeg + j * BK3;
+    if (k0 + BK3 <= kend && !sb.ragged()) sb.load_full(vb);
+    else load3<OB>(P, false, sb.rows, n0, k0, kend, t2, vb);
+    sb.advance();
+    sb.advance();
+  };
+  const int nk = (kend - kbeg + BK3 - 1) / BK3;
+  char* const a_st = lds3 + half * PLANE;            // this half's rows inside the A planes
+  if (nk > 0) {
+    load_a(0, va[0]);
+    if (half == 0) load_b(0);
+    store3<OA>(a_st, a_st + 2 * PLANE, t2, va[0]);
+    if (half == 0) store3<OB>(lds3 + 4 * PLANE, lds3 + 5 * PLANE, t2, vb);
+    if (nk > 1) {
+      load_a(1, va[1]);
+      if (half == 1) load_b(1);
+    }
+  }
+  vts_lds_barrier();
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_off[i] = lds3_off(wm * 64 + i * 16 + r, g * 16);
+    b_off[i] = lds3_off(wn * 64 + i * 16 + r, g * 16);
+  }
+  auto step = [&](int kt, auto par) {
+    constexpr int PAR = decltype(par)::value;         // kt & 1
+    if (kt + 2 < nk) {
+      load_a(kt + 2, va[PAR]);
+      if (half == PAR) load_b(kt + 2);
+    }
+    const char* a_hi = lds3 + PAR * STAGE_B;
+    const char* a_lo = a_hi + 2 * PLANE;
+    const char* b_hi = a_hi + 4 * PLANE;
+    const char* b_lo = a_hi + 5 * PLANE;
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + a_off[i]);
+      al[i] = *reinterpret_cast<const bf16x8*>(a_lo + a_off[i]);
+      bh[i] = *reinterpret_cast<const bf16x8*>(b_hi + b_off[i]);
+      bl[i] = *reinterpret_cast<const bf16x8*>(b_lo + b_off[i]);
+    }
+    // next tile -> the other stage: A chunks after MFMA groups 1, 3, 5, 7, this half's B chunks (every
+    // other step) after 9, 11, 13, 15.  On the last step stale registers go into the idle stage.
+    char* nbase = lds3 + (1 - PAR) * STAGE_B;
+    char* na = nbase + half * PLANE;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = q & 3, j = q >> 2;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      if (q & 1) {
+        const int c = q >> 1;
+        if (c < 4) store3_chunk<OA>(na, na + 2 * PLANE, t2, va[1 - PAR], c);
+        else if (half != PAR) store3_chunk<OB>(nbase + 4 * PLANE, nbase + 5 * PLANE, t2, vb, c - 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    vts_lds_barrier();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>{});
+  }
+  epilogue<CK, PLAIN>(P, acc, m0, n0, zslice, wm, wn, lane, reinterpret_cast<float*>(lds3));
+}
+
 // Sum ksplit slabs [S][M*N] into C (row stride ldc), optionally accumulating onto C: few slabs of a
 // large output, one thread per element.
 __global__ void reduce_few_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
@@ -977,8 +1098,30 @@ static bool plain_epilogue(const GemmParams& P) {
   return !P.bias0 && !P.bias1 && P.act == 0 && !P.mask_src && !P.mask_bits && !P.bits_out && !P.colpart;
 }
 
+// Split-K launches planned for it (vts_gemm_pick_ksplit) take the 256 x 128 tile.  Launches with a short
+// contraction (the LSTM input projection and data gradient: 8 to 32 k-steps per workgroup) do not: there a
+// workgroup's life is mostly prologue and epilogue, which only other resident workgroups can hide
+// (measured at 4096 x 96 windows: 13 % slower with one big workgroup per CU, against 6-11 % faster for
+// the weight gradients' 384-step loops).
+static bool use_big_tile(const GemmParams& P) { return P.mode == 1 && P.ksplit > 1 && P.big_split != 0; }
+
+template <int AK, int BKIND, int CK, bool PLAIN>
+int launch3big(const GemmParams& P, hipStream_t stream) {
+  const int tiles_m = vts_cdiv(P.M, BMB), tiles_n = vts_cdiv(P.N, BN);
+  const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
+  static unsigned long long lds_done = 0;   // per instantiation
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<AK, BKIND, CK, PLAIN>),
+                               GEMM3B_LDS_BYTES, &lds_done, "gemm_bf16x3_big"))
+    return rc;
+  hipLaunchKernelGGL((gemm_bf16x3_big_kernel<AK, BKIND, CK, PLAIN>), dim3((unsigned)nwg), dim3(512), GEMM3B_LDS_BYTES,
+                     stream, P);
+  VTS_CHECK_LAUNCH("gemm_bf16x3_big");
+  return VTS_OK;
+}
+
 template <int AK, int BKIND, int CK, bool PLAIN>
 int launch3p(const GemmParams& P, hipStream_t stream) {
+  if (use_big_tile(P)) return launch3big<AK, BKIND, CK, PLAIN>(P, stream);
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
   static unsigned long long lds_done = 0;   // per instantiation
@@ -1026,9 +1169,17 @@ int launch(const GemmParams& P, hipStream_t stream) {
 // of balance is the XCD: 32 CUs x 4 resident workgroups of this kernel (105 VGPRs, 36 KiB LDS) =
 // 128 slots.  Pick as many whole slices per XCD as fit ONE residency round (a partly filled
 // second round would run alone for a whole slice's duration), the same number on every XCD.
+// Long contractions into a small output whose height fills whole 256-row tiles are planned for the
+// 256 x 128 kernel (one workgroup per CU).
+static bool split_plan_big(int M, int N, long K, int mode) {
+  (void)N;
+  return mode == 1 && K >= 32768 && (M % BMB) == 0;
+}
+
 int vts_gemm_pick_ksplit(int M, int N, long K, int mode) {
-  const int tiles = vts_cdiv(M, BM) * vts_cdiv(N, BN);
-  const int slots_per_xcd = 32 * (mode == 1 ? 3 : 4);   // bf16x3 kernel: 160 VGPRs -> 3 workgroups per CU
+  const bool big = split_plan_big(M, N, K, mode);
+  const int tiles = vts_cdiv(M, big ? BMB : BM) * vts_cdiv(N, BN);
+  const int slots_per_xcd = big ? 32 : 32 * (mode == 1 ? 3 : 4);   // bf16x3 kernel: 160 VGPRs -> 3 workgroups per CU
   if (tiles >= 4 * slots_per_xcd || K <= 512) return 1;
   long per_xcd = slots_per_xcd / tiles;
   if (per_xcd < 1) per_xcd = 1;
@@ -1111,6 +1262,7 @@ int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs,
   P.ldb = ldx; P.ldc = F;
   P.b_map = 1; P.T = T; P.Bwin = Bwin; P.b_tshift = tshift;
   set_split(P, ksplit);
+  P.big_split = split_plan_big(P.M, P.N, P.K, mode);
   P.C = (P.ksplit > 1) ? slabs : dW;
   P.accumulate = (P.ksplit > 1) ? 0 : accumulate;
   int rc = launch<A_T16T, B_KN, C_ROW>(P, stream);
