@@ -171,6 +171,51 @@ def elbo_hbm_roofline(dev, rows=1 << 20, Ld=32, iters=10):
                     "algorithmic bytes = rows * (72*L + 16)"}
 
 
+def window_builder_hbm_roofline(dev, B, T, C, Nt=35040, iters=10, cpu=True):
+    """The step in front of the train step: one batch of standardised windows gathered on the device from a
+    series resident in HBM (one year of 15-minute LD2011-shaped load, Nt x C).  Algorithmic bytes per batch:
+    the windows written once (B*T*C*4) + the series read once (Nt*C*4) + the targets.  Beside it, the
+    reference's host path for the same batch (numpy window copies + StandardScaler.transform), timed on a
+    bounded sample of windows, and the host-to-device copy it would need."""
+    import vts
+    g = torch.Generator(device=dev).manual_seed(11)
+    series = torch.randn(Nt, C, device=dev, generator=g) * 3.0 + 1.0
+    src = vts.WindowSource(series, T, 1)
+    starts = torch.randint(0, len(src), (B,), device=dev, generator=g)
+    src.fit(starts)
+    src.batch(starts)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        src.batch(starts)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    bytes_alg = 4.0 * (B * T * C + Nt * C + B)
+    gbps = bytes_alg / (ms * 1e-3) / 1e9
+    out = {"workload": f"{B} windows x {T} steps x {C} channels gathered and standardised from a {Nt} x {C} series",
+           "ms": round(ms, 4), "windows_per_s": round(B / (ms * 1e-3), 1), "bound": "hbm", "achieved": round(gbps, 1),
+           "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+           "note": "HIP events on the launch stream around vts_windows_build (X and y kernels); algorithmic bytes = "
+                   "4*(B*T*C + Nt*C + B)"}
+    if cpu:
+        from oracle import ref_windows as RW
+        sample = min(B, 512)
+        sn, st = series.cpu().numpy(), starts[:sample].cpu().numpy()
+        mean, scale = src.x_stats[0].cpu().numpy(), src.x_stats[1].cpu().numpy()
+        t0 = time.perf_counter()
+        X, _ = RW.sliding_windows(sn, T, 1, st)
+        Xs = RW.scaler_transform(X, mean, scale)
+        xt = torch.from_numpy(Xs).to(dev)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(sample / el, 1), "unit": "windows/s", "cores": 1, "kind": "port",
+                               "sample": f"{sample} windows: numpy window gather + float64 scaler transform + upload, {el:.2f} s"}
+        del xt
+    return out
+
+
 def transformer_flops(B, T, C, d, layers, dff=2048):
     """Dense FLOPs of one train step of the transformer variant as the reference states it (every
     position through every layer): forward 2*rows*N*K per product, backward twice that (data and
@@ -444,6 +489,8 @@ def main():
         }
         if world == 1:
             out["elbo_hbm_roofline"] = elbo_hbm_roofline(dev)
+            out["window_builder_hbm_roofline"] = window_builder_hbm_roofline(dev, a.batch, a.T, a.C,
+                                                                             cpu=not a.no_cpu_baseline)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model, a.T, a.C, a.H, a.L, a.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -279,6 +279,32 @@ int vts_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
                   vts_stream_t stream);
 
+/* ---- training windows cut on the device from a series resident in HBM ----
+ * The step in front of the train step: the reference builds windows on the host, standardises the copies
+ * and uploads them -- graph/train_ld_2011.py:11-17 (create_sliding_windows), :47-59 (StandardScaler
+ * fit / transform); block-maximum targets graph/training_block_max_hurdat.py:81-86,100-106.
+ *   series [Nt][C] fp32 row-major; starts [B] int64 (device): first series row of each window
+ *   X [B][T][C] (16-byte aligned) = series rows starts[b] .. starts[b]+T-1, or null
+ *   y: VTS_TARGET_NEXT      [B][P]  column 0 of the P rows after the window (train_ld_2011.py:15)
+ *      VTS_TARGET_BLOCK_MAX [B]     their maximum, NaN-propagating like numpy.max (training_block_max_hurdat.py:103)
+ *      or null
+ *   x_mean, x_scale [C] fp64 / y_stats [2] fp64 (mean, scale), device, or null = raw values.
+ *   Standardised values equal sklearn's StandardScaler.transform on float32 input bit for bit:
+ *   f32(f64(f32(f64(x) - mean)) / scale).  A window (or target) that leaves the series is written as NaN. */
+#define VTS_TARGET_NEXT 0
+#define VTS_TARGET_BLOCK_MAX 1
+int vts_windows_build(const float* series, int64_t Nt, int64_t C, const int64_t* starts, int64_t B, int64_t T,
+                      int64_t P, int target, const double* x_mean, const double* x_scale, const double* y_stats,
+                      float* X, float* y, vts_stream_t stream);
+/* StandardScaler.fit over the rows of those windows (X.reshape(-1, C): a series row counts once per window
+ * that contains it) and over their VTS_TARGET_NEXT targets: population variance, scale = sqrt(var), 1 for a
+ * constant column.  x_stats [2][C] fp64 = means then scales; y_stats [2] fp64; either may be null.
+ * fp64 sums in a fixed order (deterministic); agrees with sklearn to ~1e-13 relative, not bit for bit. */
+size_t vts_windows_stats_workspace_bytes(int64_t Nt);
+int vts_windows_stats(const float* series, int64_t Nt, int64_t C, const int64_t* starts, int64_t B, int64_t T,
+                      int64_t P, int target, double* x_stats, double* y_stats, void* workspace,
+                      size_t workspace_bytes, vts_stream_t stream);
+
 /* out[i] = in[i] * (*scalar) */
 int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream);
 

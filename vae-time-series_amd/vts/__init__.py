@@ -13,6 +13,7 @@ from .modules import (GPDVAE, LSTM, GaussianVAE, LayerNorm, Linear, MixtureVAE, 
                       TransformerEncoderLayer, TransformerMixtureVAE)
 from .train import Adam, FlatParameters, train_step
 from .parallel import DataParallelTrainer, shard_batch
+from .windows import WindowSource, create_sliding_windows
 
 __all__ = [
     "LSTM", "Linear", "LayerNorm", "GaussianVAE", "GPDVAE", "MixtureVAE", "build_model",
@@ -20,4 +21,5 @@ __all__ = [
     "reparameterize_mixture", "gaussian_elbo", "gpd_elbo", "mixture_elbo", "mixture_split_elbo",
     "multi_head_attention", "dropout_add", "dropout_mask", "TransformerEncoderLayer", "TransformerMixtureVAE",
     "set_mode", "get_mode", "Adam", "FlatParameters", "train_step", "DataParallelTrainer", "shard_batch",
+    "WindowSource", "create_sliding_windows",
 ]

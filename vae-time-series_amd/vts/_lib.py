@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libvts_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_EXP, ACT_CLAMP_MIN, ACT_RELU_DROPOUT = 0, 1, 2, 3, 4
 GAUSSIAN, GPD, MIXTURE, MIXTURE_SPLIT = 0, 1, 2, 3
+TARGET_NEXT, TARGET_BLOCK_MAX = 0, 1
 FAMILY = {"gaussian": GAUSSIAN, "gpd": GPD, "mixture": MIXTURE}
 
 _i64, _f32, _int, _ptr, _sz, _u64 = C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_uint64
@@ -75,6 +76,9 @@ SIGNATURES = {
     "vts_dropout_mask": (_int, [_u64, _f32, _ptr, _i64, _ptr]),
     "vts_adam_step": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr]),
     "vts_scale": (_int, [_ptr, _ptr, _ptr, _i64, _ptr]),
+    "vts_windows_build": (_int, [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "vts_windows_stats_workspace_bytes": (_sz, [_i64]),
+    "vts_windows_stats": (_int, [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr, _sz, _ptr]),
 }
 
 _lib: Optional[C.CDLL] = None
