@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="mixture", choices=["gaussian", "gpd", "mixture", "transformer"],
+    ap.add_argument("--model", default="mixture", choices=["gaussian", "gpd", "mixture", "mixture3", "transformer"],
                     help="the three LSTM-VAE families (headline: mixture) or the transformer-encoder mixture VAE")
     ap.add_argument("--d-model", type=int, default=64)
     ap.add_argument("--nhead", type=int, default=8)
@@ -390,9 +390,13 @@ def main():
     torch.manual_seed(1234)                     # identical replicas on every rank
     model = vts.build_model(a.model, a.C, a.H, a.L, 1).to(dev)
     model.train()
+    if a.model == "mixture3":                   # a threshold inside the data and some exact zeros: all three loss terms live
+        model.threshold = 0.8
     trainer = vts.DataParallelTrainer(model, lr=1e-3)
     torch.manual_seed(4321 + rank)              # rank-offset noise streams
     x, y = synth_windows(a.batch, a.T, a.C, rank, dev)
+    if a.model == "mixture3":
+        y[::16] = 0.0
 
     def sync():
         if launched:

@@ -279,6 +279,36 @@ int vts_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
                   vts_stream_t stream);
 
+/* ---- three-component latent mixture (Gaussian / GPD / Bernoulli) ----
+ * graph/vae_mixture_graph_model.py with use_gcn = use_d_knn = False, use_gpd = use_bernoulli = True, the
+ * configuration of graph/train_ld_2011.py:91.  Latent tensors [B][L], recon / y / choice [B] (future_steps 1),
+ * pi [3] = pi_params.
+ * reparameterize (:182-209): row b takes the Gaussian sample if choice[b] < p0, the GPD sample if
+ * choice[b] < p0 + p1, else the Bernoulli sample, (p0, p1, p2) = softmax(pi).  `bern` holds either the 0/1
+ * sample itself (bern_is_uniform = 0: replay of a recorded torch.bernoulli draw) or a uniform draw that is
+ * compared with sigmoid(logits) here (bern_is_uniform = 1, :21-23).  The backward gives the sampling
+ * gradients of mean / logvar / scale / shape; the pick and the Bernoulli sample carry none. */
+int vts_reparam3_fwd(const float* mean, const float* logvar, const float* scale, const float* shape,
+                     const float* logits, const float* bern, int bern_is_uniform, const float* eps, const float* u,
+                     const float* choice, const float* pi, float* z, int64_t B, int64_t L, vts_stream_t stream);
+int vts_reparam3_bwd(const float* dz, const float* logvar, const float* scale, const float* shape, const float* eps,
+                     const float* u, const float* choice, const float* pi, float* dmean, float* dlogvar, float* dscale,
+                     float* dshape, int64_t B, int64_t L, vts_stream_t stream);
+/* loss_function (:222-285) with rows classed by y (classify_observations :26-50: zero if y == 0, else normal
+ * if y <= threshold, else extreme):
+ *   loss = p0*(mse(recon, y | normal) + beta*KL_gauss) + p1*mean_{extreme rows, L}[log s + (1 + 1/xi)*log(1 + xi*(y-u)/s)]
+ *        + p2*(-mean_{zero rows, L}[y*log sig(l) + (1-y)*log(1 - sig(l))]);  a class without rows contributes 0,
+ *   except that an empty normal class makes the loss NaN (mse of an empty selection), as in the reference.
+ * state: 16 floats written by the forward and read by the backward; gout: [1] upstream gradient. */
+size_t vts_elbo3_workspace_bytes(int64_t B, int64_t L);
+int vts_elbo3_fwd(const float* recon, const float* y, const float* mean, const float* logvar, const float* scale,
+                  const float* shape, const float* logits, const float* pi, float threshold, float beta, float* loss,
+                  float* state, void* workspace, size_t workspace_bytes, int64_t B, int64_t L, vts_stream_t stream);
+int vts_elbo3_bwd(const float* recon, const float* y, const float* mean, const float* logvar, const float* scale,
+                  const float* shape, const float* logits, float threshold, float beta, const float* state,
+                  const float* gout, float* drecon, float* dmean, float* dlogvar, float* dscale, float* dshape,
+                  float* dlogits, float* dpi, int64_t B, int64_t L, vts_stream_t stream);
+
 /* ---- training windows cut on the device from a series resident in HBM ----
  * The step in front of the train step: the reference builds windows on the host, standardises the copies
  * and uploads them -- graph/train_ld_2011.py:11-17 (create_sliding_windows), :47-59 (StandardScaler

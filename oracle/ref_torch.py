@@ -116,6 +116,16 @@ def encode_mixture(sd: State, x: Tensor, enc_keep: Optional[Tensor], stock: bool
     return mean, logvar, scale, shape
 
 
+def encode_mixture3(sd: State, x: Tensor, enc_keep: Optional[Tensor], stock: bool = True):
+    """graph/vae_mixture_graph_model.py:113-136 with use_gcn=False: the mixture heads + the Bernoulli logits."""
+    hid = _trunk(sd, x, enc_keep, stock)
+    mean = _linear(sd, "encoder.mean_layer_normal", hid)
+    logvar = _linear(sd, "encoder.logvar_layer_normal", hid)
+    scale = torch.exp(_linear(sd, "encoder.scale_layer_extreme", hid))
+    shape = torch.clamp(_linear(sd, "encoder.shape_layer_extreme", hid), min=1e-6)
+    return mean, logvar, scale, shape, _linear(sd, "encoder.logits_layer_zero", hid)
+
+
 # ------------------------------------------------------------------ reparameterise
 def reparam_gaussian(mean: Tensor, logvar: Tensor, eps: Tensor) -> Tensor:
     """gaussian-lstm-DE.py:55-58 ; mixture-vae-DE.py:10-13 with eps fed in."""
@@ -133,6 +143,15 @@ def mixture_select(zg: Tensor, zp: Tensor, pi_params: Tensor, choice: Tensor) ->
     choice[i] < softmax(pi)[0].  The comparison carries no gradient to pi_params."""
     p0 = torch.softmax(pi_params.detach(), dim=0)[0]
     return torch.where((choice < p0)[:, None], zg, zp)
+
+
+def mixture3_select(zg: Tensor, zp: Tensor, zb: Tensor, pi_params: Tensor, choice: Tensor) -> Tensor:
+    """graph/vae_mixture_graph_model.py:191-198: rows with choice < p0 take the Gaussian sample, rows with
+    p0 <= choice < p0 + p1 the GPD sample, the rest the Bernoulli sample (which carries no gradient)."""
+    p = torch.softmax(pi_params.detach(), dim=0)
+    first = (choice < p[0])[:, None]
+    second = ((choice >= p[0]) & (choice < p[0] + p[1]))[:, None]
+    return torch.where(first, zg, torch.where(second, zp, zb.detach()))
 
 
 # ----------------------------------------------------------------------- decoders
@@ -180,6 +199,28 @@ def loss_mixture(recon, y, mean, logvar, scale, shape, pi_params, threshold=95.0
     return F.mse_loss(recon, y, reduction="mean") + l_g + l_p
 
 
+def loss_mixture3(recon, y, mean, logvar, scale, shape, logits, pi_params, threshold, beta=0.001) -> Tensor:
+    """graph/vae_mixture_graph_model.py:222-285 with use_gpd = use_bernoulli = True and no D-KNN term;
+    classify_observations :26-50.  y is [B, 1].  A class without rows contributes the constant 0 (:251,:266),
+    an empty normal class makes the masked MSE NaN."""
+    pi = torch.softmax(pi_params, dim=0)
+    zero = y == 0
+    normal = (y <= threshold) & ~zero
+    extreme = (y > threshold) & ~zero
+    r_g = F.mse_loss(recon[normal], y[normal], reduction="mean")
+    total = pi[0] * (r_g + beta * kl_gaussian(mean, logvar))
+    em = extreme.squeeze(-1)
+    if int(em.sum()) != 0:
+        excess = y[em] - threshold
+        sc, sh = scale[em], shape[em]
+        total = total + pi[1] * torch.mean(torch.log(sc) + (1 + 1 / sh) * torch.log(1 + sh * excess / sc))
+    zm = zero.squeeze(-1)
+    if int(zm.sum()) != 0:
+        yz, lz = y[zm], logits[zm]
+        total = total + pi[2] * -torch.mean(yz * torch.log(torch.sigmoid(lz)) + (1 - yz) * torch.log(1 - torch.sigmoid(lz)))
+    return total
+
+
 # ------------------------------------------------------------------ whole forward
 def forward_loss(kind: str, sd: State, x: Tensor, y: Tensor, noise: Dict[str, Tensor],
                  threshold: float = 95.0, beta: float = 0.001, stock: bool = True):
@@ -208,6 +249,15 @@ def forward_loss(kind: str, sd: State, x: Tensor, y: Tensor, noise: Dict[str, Te
                             threshold, beta)
         return loss, {"recon": recon, "mean": mean, "logvar": logvar, "scale": scale,
                       "shape": shape, "z": z}
+    if kind == "mixture3":
+        mean, logvar, scale, shape, logits = encode_mixture3(sd, x, noise.get("enc_keep"), stock)
+        zg = reparam_gaussian(mean, logvar, noise["eps"])
+        zp = reparam_gpd(scale, shape, noise["u"])
+        z = mixture3_select(zg, zp, noise["bern"], sd["pi_params"], noise["choice"])
+        recon = decode_deep(sd, z, noise.get("dec_keep"))
+        loss = loss_mixture3(recon, y, mean, logvar, scale, shape, logits, sd["pi_params"], threshold, beta)
+        return loss, {"recon": recon, "mean": mean, "logvar": logvar, "scale": scale, "shape": shape,
+                      "logits": logits, "z": z}
     raise ValueError(kind)
 
 
@@ -242,6 +292,8 @@ def param_shapes(kind: str, C: int, H: int, L: int, fs: int = 1) -> Dict[str, Tu
     shp: Dict[str, Tuple[int, ...]] = {}
     if kind == "mixture":
         shp["pi_params"] = (2,)
+    if kind == "mixture3":
+        shp["pi_params"] = (3,)
     layers = 1 if kind == "gaussian" else 3
     for k in range(layers):
         cin = C if k == 0 else H
@@ -264,11 +316,13 @@ def param_shapes(kind: str, C: int, H: int, L: int, fs: int = 1) -> Dict[str, Tu
     shp["encoder.layer_norm.bias"] = (H,)
     lin("encoder.fc1", 128, H)
     lin("encoder.fc2", 64, 128)
-    if kind == "mixture":
+    if kind in ("mixture", "mixture3"):
         lin("encoder.mean_layer_normal", L, 64)
         lin("encoder.logvar_layer_normal", L, 64)
     lin("encoder.scale_layer_extreme", L, 64)
     lin("encoder.shape_layer_extreme", L, 64)
+    if kind == "mixture3":
+        lin("encoder.logits_layer_zero", L, 64)
     lin("decoder.fc1", 128, L)
     lin("decoder.fc2", 500, 128)
     lin("decoder.out", fs, 500)
@@ -283,7 +337,7 @@ def init_state(kind: str, C: int, H: int, L: int, fs: int = 1, seed: int = 0) ->
     sd: State = {}
     for name, shape in param_shapes(kind, C, H, L, fs).items():
         if name == "pi_params":
-            sd[name] = torch.tensor([3.0, 0.01])
+            sd[name] = torch.tensor([3.0, 0.01, 0.01] if kind == "mixture3" else [3.0, 0.01])
         elif name == "encoder.layer_norm.weight":
             sd[name] = torch.ones(shape)
         elif name == "encoder.layer_norm.bias":
@@ -312,7 +366,12 @@ def draw_noise(kind: str, B: int, L: int, seed: int = 0, train: bool = True) -> 
     if kind == "mixture":
         n["choice"] = torch.rand(B, generator=g)
         n["eps"] = torch.randn(B, L, generator=g)
+    if kind == "mixture3":   # eps, u, Bernoulli sample, choice (graph/vae_mixture_graph_model.py:183-191)
+        n["eps"] = torch.randn(B, L, generator=g)
     n["u"] = torch.rand(B, L, generator=g)
+    if kind == "mixture3":
+        n["bern"] = (torch.rand(B, L, generator=g) < 0.5).float()
+        n["choice"] = torch.rand(B, generator=g)
     if train:
         n["dec_keep"] = (torch.rand(B, 500, generator=g) >= DROP_P).float()
     return n

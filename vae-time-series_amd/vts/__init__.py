@@ -8,9 +8,10 @@ from . import _lib
 from .functional import get_mode, set_mode
 from .functional import (gaussian_elbo, gpd_elbo, layer_norm, linear, lstm, mixture_elbo,
                          reparameterize_gaussian, reparameterize_gpd, reparameterize_mixture,
-                         mixture_split_elbo, multi_head_attention, dropout_add, dropout_mask)
+                         mixture_split_elbo, multi_head_attention, dropout_add, dropout_mask,
+                         reparameterize_mixture3, mixture3_elbo)
 from .modules import (GPDVAE, LSTM, GaussianVAE, LayerNorm, Linear, MixtureVAE, build_model,
-                      TransformerEncoderLayer, TransformerMixtureVAE)
+                      TransformerEncoderLayer, TransformerMixtureVAE, ThreeComponentVAE)
 from .train import Adam, FlatParameters, train_step
 from .parallel import DataParallelTrainer, shard_batch
 from .windows import WindowSource, create_sliding_windows
@@ -21,5 +22,5 @@ __all__ = [
     "reparameterize_mixture", "gaussian_elbo", "gpd_elbo", "mixture_elbo", "mixture_split_elbo",
     "multi_head_attention", "dropout_add", "dropout_mask", "TransformerEncoderLayer", "TransformerMixtureVAE",
     "set_mode", "get_mode", "Adam", "FlatParameters", "train_step", "DataParallelTrainer", "shard_batch",
-    "WindowSource", "create_sliding_windows",
+    "WindowSource", "create_sliding_windows", "ThreeComponentVAE", "reparameterize_mixture3", "mixture3_elbo",
 ]

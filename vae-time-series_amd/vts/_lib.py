@@ -76,6 +76,11 @@ SIGNATURES = {
     "vts_dropout_mask": (_int, [_u64, _f32, _ptr, _i64, _ptr]),
     "vts_adam_step": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr]),
     "vts_scale": (_int, [_ptr, _ptr, _ptr, _i64, _ptr]),
+    "vts_reparam3_fwd": (_int, [_ptr] * 6 + [_int] + [_ptr] * 5 + [_i64, _i64, _ptr]),
+    "vts_reparam3_bwd": (_int, [_ptr] * 12 + [_i64, _i64, _ptr]),
+    "vts_elbo3_workspace_bytes": (_sz, [_i64, _i64]),
+    "vts_elbo3_fwd": (_int, [_ptr] * 8 + [_f32, _f32, _ptr, _ptr, _ptr, _sz, _i64, _i64, _ptr]),
+    "vts_elbo3_bwd": (_int, [_ptr] * 7 + [_f32, _f32] + [_ptr] * 9 + [_i64, _i64, _ptr]),
     "vts_windows_build": (_int, [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "vts_windows_stats_workspace_bytes": (_sz, [_i64]),
     "vts_windows_stats": (_int, [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr, _sz, _ptr]),

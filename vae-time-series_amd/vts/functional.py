@@ -665,3 +665,96 @@ def dropout_mask(seed: int, drop_p: float, shape, device) -> torch.Tensor:
     keep = torch.empty(shape, dtype=torch.uint8, device=device)
     L.check(lib.vts_dropout_mask(seed, drop_p, L.bptr(keep), keep.numel(), L.stream()), "vts_dropout_mask")
     return keep
+
+
+# ------------------------------------------------- three-component mixture (Gaussian / GPD / Bernoulli)
+class _Reparam3(torch.autograd.Function):
+    """vae-models/graph/vae_mixture_graph_model.py:182-209 (use_gpd and use_bernoulli on)."""
+
+    @staticmethod
+    def forward(ctx, mean, logvar, scale, shape, logits, pi, bern, bern_is_uniform, eps, u, choice):
+        lib = L.load()
+        _need_gpu(mean)
+        B, Ld = mean.shape
+        mean, logvar, scale, shape, logits, bern, eps, u, choice = [
+            _c(t) for t in (mean.detach(), logvar.detach(), scale.detach(), shape.detach(), logits.detach(), bern, eps, u, choice)]
+        pi_d = pi.detach().contiguous()
+        z = torch.empty(B, Ld, device=mean.device, dtype=torch.float32)
+        L.check(L.timer.call("reparam3_fwd", lib.vts_reparam3_fwd, L.ptr(mean), L.ptr(logvar), L.ptr(scale), L.ptr(shape),
+                             L.ptr(logits), L.ptr(bern), int(bern_is_uniform), L.ptr(eps), L.ptr(u), L.ptr(choice),
+                             L.ptr(pi_d), L.ptr(z), B, Ld, L.stream()), "vts_reparam3_fwd")
+        ctx.save_for_backward(logvar, scale, shape, eps, u, choice, pi_d)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = L.load()
+        logvar, scale, shape, eps, u, choice, pi_d = ctx.saved_tensors
+        dz = dz.contiguous()
+        B, Ld = dz.shape
+        dmean, dlogvar, dscale, dshape = [torch.empty(B, Ld, device=dz.device, dtype=torch.float32) for _ in range(4)]
+        L.check(L.timer.call("reparam3_bwd", lib.vts_reparam3_bwd, L.ptr(dz), L.ptr(logvar), L.ptr(scale), L.ptr(shape),
+                             L.ptr(eps), L.ptr(u), L.ptr(choice), L.ptr(pi_d), L.ptr(dmean), L.ptr(dlogvar), L.ptr(dscale),
+                             L.ptr(dshape), B, Ld, L.stream()), "vts_reparam3_bwd")
+        return dmean, dlogvar, dscale, dshape, None, None, None, None, None, None, None
+
+
+def reparameterize_mixture3(mean, logvar, scale, shape, logits, pi_params, choice=None, eps=None, u=None, bern=None):
+    """z of the three-component model.  Draws not fed in are made on the device in the reference's order
+    (eps, u, the Bernoulli draw, choice); ``bern`` is a recorded 0/1 sample when given."""
+    dev = mean.device
+    if eps is None:
+        eps = torch.randn_like(mean)
+    if u is None:
+        u = torch.rand(mean.shape, device=dev)
+    uniform = bern is None
+    if uniform:
+        bern = torch.rand(mean.shape, device=dev)
+    if choice is None:
+        choice = torch.rand(mean.shape[0], device=dev)
+    return _Reparam3.apply(mean, logvar, scale, shape, logits, pi_params, bern, uniform, eps, u, choice)
+
+
+class _Elbo3(torch.autograd.Function):
+    """vae-models/graph/vae_mixture_graph_model.py:222-285 (use_gpd and use_bernoulli on, no D-KNN term)."""
+
+    @staticmethod
+    def forward(ctx, recon, y, mean, logvar, scale, shape, logits, pi, threshold: float, beta: float):
+        lib = L.load()
+        _need_gpu(recon)
+        B, Ld = mean.shape
+        if recon.numel() != B or y.numel() != B:
+            raise NotImplementedError("three-component loss: future_steps must be 1 (the reference indexes the "
+                                      "[B, L] latent tensors with masks made from y)")
+        recon, y, mean, logvar, scale, shape, logits = [_c(t.detach()) for t in (recon, y, mean, logvar, scale, shape, logits)]
+        pi_d = pi.detach().contiguous()
+        loss = torch.empty((), device=recon.device, dtype=torch.float32)
+        state = torch.empty(16, device=recon.device, dtype=torch.float32)
+        wsb = lib.vts_elbo3_workspace_bytes(B, Ld)
+        ws = L.workspace(wsb, recon.device)
+        L.check(L.timer.call("elbo3_fwd", lib.vts_elbo3_fwd, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale),
+                             L.ptr(shape), L.ptr(logits), L.ptr(pi_d), float(threshold), float(beta), L.ptr(loss), L.ptr(state),
+                             L.wptr(ws), wsb, B, Ld, L.stream()), "vts_elbo3_fwd")
+        ctx.save_for_backward(recon, y, mean, logvar, scale, shape, logits, state)
+        ctx.threshold, ctx.beta = float(threshold), float(beta)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        recon, y, mean, logvar, scale, shape, logits, state = ctx.saved_tensors
+        B, Ld = mean.shape
+        dev = mean.device
+        gout = gout.contiguous().reshape(1)
+        drecon = torch.empty_like(recon)
+        dmean, dlogvar, dscale, dshape, dlogits = [torch.empty(B, Ld, device=dev, dtype=torch.float32) for _ in range(5)]
+        dpi = torch.empty(3, device=dev, dtype=torch.float32)
+        L.check(L.timer.call("elbo3_bwd", lib.vts_elbo3_bwd, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale),
+                             L.ptr(shape), L.ptr(logits), ctx.threshold, ctx.beta, L.ptr(state), L.ptr(gout), L.ptr(drecon),
+                             L.ptr(dmean), L.ptr(dlogvar), L.ptr(dscale), L.ptr(dshape), L.ptr(dlogits), L.ptr(dpi), B, Ld,
+                             L.stream()), "vts_elbo3_bwd")
+        return drecon, None, dmean, dlogvar, dscale, dshape, dlogits, dpi, None, None
+
+
+def mixture3_elbo(recon, y, mean, logvar, threshold: float, scale, shape, logits, pi_params, beta: float = 0.001) -> torch.Tensor:
+    return _Elbo3.apply(recon, y, mean, logvar, scale, shape, logits, pi_params, threshold, beta)

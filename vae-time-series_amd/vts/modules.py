@@ -237,6 +237,68 @@ class MixtureVAE(nn.Module):
         return F.mixture_elbo(reconstructed, y, mean, logvar, scale, shape, self.pi_params, thr, self.beta, kl=kl)
 
 
+# ------------------------------------------------- three-component mixture VAE (graph model, no GCN)
+class ThreeComponentEncoder(DeepEncoder):
+    """LSTM_GCN_Encoder of vae-models/graph/vae_mixture_graph_model.py:74-136 with use_gcn=False: the mixture
+    encoder plus the Bernoulli head ``logits_layer_zero``."""
+
+    def __init__(self, input_dim, lstm_output_dim, latent_dim):
+        super().__init__(input_dim, lstm_output_dim, latent_dim, gaussian_heads=True)
+        self.logits_layer_zero = Linear(64, latent_dim)
+
+    def forward(self, x, noise: Noise = None):
+        _, (h_n, _) = self.lstm(x)
+        h = self.layer_norm(h_n[-1])
+        hidden = self.fc1(h, act=L.ACT_RELU)
+        keep = _keep_mask(noise, "enc_keep", self.training, (hidden.shape[0], 64), hidden.device)
+        hidden = self.fc2(hidden, act=L.ACT_RELU_DROPOUT, keep=keep)
+        return (self.mean_layer_normal(hidden), self.logvar_layer_normal(hidden),
+                self.scale_layer_extreme(hidden, act=L.ACT_EXP), self.shape_layer_extreme(hidden, act=L.ACT_CLAMP_MIN),
+                self.logits_layer_zero(hidden))
+
+
+class ThreeComponentVAE(nn.Module):
+    """``VAE`` of vae-models/graph/vae_mixture_graph_model.py:155-285 in the configuration its LD2011 driver
+    uses (graph/train_ld_2011.py:91): Gaussian + GPD + Bernoulli components, no GCN layer, no D-KNN imputer.
+    Constructor, ``forward`` and ``loss_function`` keep the reference's argument order; the graph options raise."""
+    kind = "mixture3"
+
+    def __init__(self, input_dim, lstm_output_dim, gcn_output_dim, latent_dim, future_steps, beta=0.001,
+                 use_d_knn=False, use_gcn=False, use_gpd=True, use_bernoulli=True):
+        super().__init__()
+        if use_gcn or use_d_knn:
+            raise NotImplementedError("vts.ThreeComponentVAE: the GCN layer and the D-KNN imputer are not built")
+        if not (use_gpd and use_bernoulli):
+            raise NotImplementedError("vts.ThreeComponentVAE: use vts.MixtureVAE / vts.GaussianVAE for fewer components")
+        if future_steps != 1:
+            raise NotImplementedError("vts.ThreeComponentVAE: future_steps must be 1 (the reference's loss masks the "
+                                      "[B, L] latent tensors with masks made from y)")
+        self.encoder = ThreeComponentEncoder(input_dim, lstm_output_dim, latent_dim)
+        self.decoder = DeepDecoder(latent_dim, future_steps)
+        self.beta = beta
+        self.threshold = None
+        self.pi_params = nn.Parameter(torch.tensor([3.0, 0.01, 0.01]))
+
+    def reparameterize(self, mean, logvar, scale, shape, logits, choice=None, eps=None, u=None, bern=None):
+        return F.reparameterize_mixture3(mean, logvar, scale, shape, logits, self.pi_params, choice, eps, u, bern)
+
+    def forward(self, x_full, x_missing=None, edge_index=None, noise: Noise = None):
+        # draw order of the reference: encoder dropout, eps, u, Bernoulli, choice, decoder dropout
+        mean, logvar, scale, shape, logits = self.encoder(x_full, noise)
+        n = noise or {}
+        z = F.reparameterize_mixture3(mean, logvar, scale, shape, logits, self.pi_params, n.get("choice"), n.get("eps"),
+                                      n.get("u"), n.get("bern"))
+        return self.decoder(z, noise), mean, logvar, scale, shape, logits
+
+    def loss_function(self, reconstructed, y, z_mean_normal, z_log_var_normal, threshold=None, z_scale_extreme=None,
+                      z_shape_extreme=None, z_logits_zero=None, x_full=None, x_missing=None):
+        thr = self.threshold if threshold is None else threshold
+        if thr is None:
+            raise ValueError("ThreeComponentVAE.loss_function needs a threshold")
+        return F.mixture3_elbo(reconstructed, y, z_mean_normal, z_log_var_normal, float(thr), z_scale_extreme,
+                               z_shape_extreme, z_logits_zero, self.pi_params, self.beta)
+
+
 # ------------------------------------------------------------------- transformer mixture VAE
 TRANSFORMER_DROP_P = 0.2   # nn.TransformerEncoderLayer(dropout=0.2), Decoder nn.Dropout(0.2)
 
@@ -400,4 +462,8 @@ def build_model(kind: str, input_dim: int, lstm_output_dim: int, latent_dim: int
         return GPDVAE(input_dim, lstm_output_dim, latent_dim, future_steps, beta, threshold)
     if kind == "mixture":
         return MixtureVAE(input_dim, lstm_output_dim, latent_dim, future_steps, beta, threshold)
+    if kind == "mixture3":
+        m = ThreeComponentVAE(input_dim, lstm_output_dim, 0, latent_dim, future_steps, beta)
+        m.threshold = threshold
+        return m
     raise ValueError(f"unknown model kind {kind!r}")
