@@ -335,6 +335,13 @@ int vts_windows_stats(const float* series, int64_t Nt, int64_t C, const int64_t*
                       int64_t P, int target, double* x_stats, double* y_stats, void* workspace,
                       size_t workspace_bytes, vts_stream_t stream);
 
+/* The same update with the step counter kept on the device, for callers that record the step's launches once
+ * and replay them (HIP graphs): step_state is 16 bytes of device memory, [int64 step][2 floats of scratch],
+ * zero before the first step; each call increments the counter and uses the new value. */
+int vts_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          int64_t* step_state, float lr, float beta1, float beta2, float eps, float grad_scale,
+                          vts_stream_t stream);
+
 /* out[i] = in[i] * (*scalar) */
 int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream);
 

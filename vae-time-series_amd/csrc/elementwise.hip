@@ -628,6 +628,36 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// Step counter on the device, for callers that replay a recorded launch sequence (HIP graphs): one thread
+// advances the counter and leaves this step's bias corrections beside it; the update kernel reads them.
+// state: [int64 step][float 1 - b1^t][float sqrt(1 - b2^t)]
+__global__ void adam_advance_kernel(long long* state, float b1, float b2) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long t = state[0] + 1;
+    state[0] = t;
+    float* coef = reinterpret_cast<float*>(state + 1);
+    coef[0] = (float)(1.0 - pow((double)b1, (double)t));
+    coef[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  }
+}
+__global__ void adam_counted_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                    const long long* __restrict__ state, float gscale) {
+  const float* coef = reinterpret_cast<const float*>(state + 1);
+  const float step_size = lr / coef[0];
+  const float bc2_sqrt = coef[1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 // tile16 [Mp*T, N] (window row order) <-> row-major [B, T, N]
 __global__ void tile16_from_rows_kernel(const float* __restrict__ rows, float* __restrict__ tiled, int B, int T,
                                         int N, int to_rows) {
@@ -876,6 +906,16 @@ int vts_ew_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1,
                      bc2_sqrt, gscale);
   VTS_CHECK_LAUNCH("adam");
+  return VTS_OK;
+}
+
+int vts_ew_adam_counted(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        long long* state, float gscale, hipStream_t st) {
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, st, state, b1, b2);
+  VTS_CHECK_LAUNCH("adam_advance");
+  hipLaunchKernelGGL(adam_counted_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, state,
+                     gscale);
+  VTS_CHECK_LAUNCH("adam_counted");
   return VTS_OK;
 }
 

@@ -6,6 +6,8 @@
 #include <string.h>
 
 // ---- internal entry points (gemm_f32.hip, lstm_rec_f32.hip, elementwise.hip) -------------------
+int vts_ew_adam_counted(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        long long* state, float gscale, hipStream_t st);
 int vts_gemm_pick_ksplit(int M, int N, long K, int mode);
 size_t vts_gemm_slab_bytes(int M, int N, int ksplit);
 int vts_gemm_inproj(const float* X, const float* W, const float* b0, const float* b1, float* G, int Bwin, int T,
@@ -681,6 +683,15 @@ int vts_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   return vts_ew_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
                      grad_scale, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          int64_t* step_state, float lr, float beta1, float beta2, float eps, float grad_scale,
+                          vts_stream_t stream) {
+  VTS_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_state && n > 0, "adam_step_counted: bad arguments");
+  VTS_REQUIRE((reinterpret_cast<uintptr_t>(step_state) & 7u) == 0, "adam_step_counted: step_state must be 8-byte aligned");
+  return vts_ew_adam_counted(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                             reinterpret_cast<long long*>(step_state), grad_scale, reinterpret_cast<hipStream_t>(stream));
 }
 
 int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream) {

@@ -12,7 +12,7 @@ from .functional import (gaussian_elbo, gpd_elbo, layer_norm, linear, lstm, mixt
                          reparameterize_mixture3, mixture3_elbo)
 from .modules import (GPDVAE, LSTM, GaussianVAE, LayerNorm, Linear, MixtureVAE, build_model,
                       TransformerEncoderLayer, TransformerMixtureVAE, ThreeComponentVAE)
-from .train import Adam, FlatParameters, train_step
+from .train import Adam, FlatParameters, GraphedTrainStep, train_step
 from .parallel import DataParallelTrainer, shard_batch
 from .windows import WindowSource, create_sliding_windows
 
@@ -21,6 +21,6 @@ __all__ = [
     "lstm", "linear", "layer_norm", "reparameterize_gaussian", "reparameterize_gpd",
     "reparameterize_mixture", "gaussian_elbo", "gpd_elbo", "mixture_elbo", "mixture_split_elbo",
     "multi_head_attention", "dropout_add", "dropout_mask", "TransformerEncoderLayer", "TransformerMixtureVAE",
-    "set_mode", "get_mode", "Adam", "FlatParameters", "train_step", "DataParallelTrainer", "shard_batch",
+    "set_mode", "get_mode", "Adam", "FlatParameters", "train_step", "GraphedTrainStep", "DataParallelTrainer", "shard_batch",
     "WindowSource", "create_sliding_windows", "ThreeComponentVAE", "reparameterize_mixture3", "mixture3_elbo",
 ]

@@ -62,14 +62,27 @@ class Adam:
         self.exp_avg = torch.zeros_like(flat.data)
         self.exp_avg_sq = torch.zeros_like(flat.data)
         self.step_count = 0
+        self.step_state: Optional[torch.Tensor] = None   # device-side counter (see count_on_device)
 
     def zero_grad(self) -> None:
         self.flat.zero_grad()
 
+    def count_on_device(self) -> None:
+        """Keep the step counter in device memory from now on, so that a recorded step can be replayed
+        (GraphedTrainStep): [int64 step, 2 floats of scratch]."""
+        if self.step_state is None:
+            self.step_state = torch.zeros(2, dtype=torch.int64, device=self.flat.data.device)
+            self.step_state[0] = self.step_count
+
     def step(self, grad_scale: float = 1.0) -> None:
         lib = L.load()
-        self.step_count += 1
         f = self.flat
+        if self.step_state is not None:
+            L.check(lib.vts_adam_step_counted(L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                              f.numel, L.wptr(self.step_state), self.lr, self.betas[0], self.betas[1],
+                                              self.eps, grad_scale, L.stream()), "vts_adam_step_counted")
+            return
+        self.step_count += 1
         L.check(lib.vts_adam_step(L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                   f.numel, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
                                   grad_scale, L.stream()), "vts_adam_step")
@@ -98,3 +111,43 @@ def train_step(model: nn.Module, opt: Optional[Adam], x: torch.Tensor, y: torch.
     if opt is not None:
         opt.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """One optimisation step recorded as a HIP graph and replayed: a step of the reference's own sizes
+    (16 windows x 16 steps, hidden 64) is a hundred launches of a few microseconds each, so the host's
+    launch rate, not the GPU, sets its duration; a replay submits them in one call.
+
+    ``x`` / ``y`` fix the batch shape; later calls copy their batch into those buffers.  Random draws are
+    made on the device inside the graph (torch's generator is graph-aware), the Adam step counter lives on
+    the device.  Building the graph leaves parameters and optimizer state as they were.  Single process
+    only (a gradient all-reduce is not recorded); models whose dropout seeds are drawn on the host
+    (the transformer variant) are refused."""
+
+    def __init__(self, model: nn.Module, opt: Adam, x: torch.Tensor, y: torch.Tensor, warmup: int = 3):
+        if getattr(model, "kind", None) == "transformer":
+            raise NotImplementedError("GraphedTrainStep: the transformer variant draws its dropout seeds on the host")
+        if not x.is_cuda:
+            raise RuntimeError("GraphedTrainStep needs device tensors")
+        self.model, self.opt = model, opt
+        self.x, self.y = x.clone(), y.clone()
+        opt.count_on_device()
+        keep = [t.clone() for t in (opt.flat.data, opt.exp_avg, opt.exp_avg_sq, opt.step_state)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # the library's one-off set-up calls (LDS opt-in) happen here, not in the capture
+            for _ in range(warmup):
+                train_step(model, opt, self.x, self.y)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(model, opt, self.x, self.y)
+        for dst, src in zip((opt.flat.data, opt.exp_avg, opt.exp_avg_sq, opt.step_state), keep):
+            dst.copy_(src)
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """Runs the recorded step on this batch; the returned loss tensor is overwritten by the next call."""
+        self.x.copy_(x)
+        self.y.copy_(y)
+        self.graph.replay()
+        return self.loss
