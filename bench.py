@@ -357,11 +357,32 @@ def bench_transformer(a, dev, world, rank, launched):
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_transformer(a.T, a.C, a.d_model, a.nhead, a.layers, a.L,
                                                        min(a.cpu_sample, 64))
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
+
+
+_RESULT_FD = None
+
+
+def quiet_stdout():
+    """Everything but the result line goes to stderr: libraries (RCCL's version banner at communicator set-up,
+    for one) print to the process's stdout, which the caller reads as ONE JSON line."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(line: str) -> None:
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_RESULT_FD, (line + "\n").encode())
 
 
 def main():
     a = parse()
+    quiet_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -497,7 +518,7 @@ def main():
                                                                              cpu=not a.no_cpu_baseline)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model, a.T, a.C, a.H, a.L, a.cpu_sample)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if launched:
         dist.barrier()
         dist.destroy_process_group()
