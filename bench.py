@@ -54,6 +54,8 @@ def parse():
                     help="arithmetic of the LSTM's dense products: fp32 operands on the f32 matrix cores, or each "
                          "fp32 operand split into two bf16 and three bf16 products per fp32 product (fp32 "
                          "accumulate); both hold the 1e-4 parity bound.  Heads, cell update and ELBO are f32.")
+    ap.add_argument("--exact-loss", action="store_true",
+                    help="data-parallel runs: loss of the concatenated batch (one more all-reduce of 8 floats per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="windows in the CPU baseline sample")
     return ap.parse_args()
@@ -275,7 +277,7 @@ def bench_transformer(a, dev, world, rank, launched):
     torch.manual_seed(1234)
     model = vts.TransformerMixtureVAE(a.C, a.d_model, a.layers, a.nhead, a.L, 1).to(dev)
     model.train()
-    trainer = vts.DataParallelTrainer(model, lr=1e-3)
+    trainer = vts.DataParallelTrainer(model, lr=1e-3, exact_loss=a.exact_loss)
     torch.manual_seed(4321 + rank)
     x, y = synth_windows(a.batch, a.T, a.C, rank, dev)
     model.threshold = float(y.abs().median())    # both selections of the loss populated on every rank
@@ -413,7 +415,7 @@ def main():
     model.train()
     if a.model == "mixture3":                   # a threshold inside the data and some exact zeros: all three loss terms live
         model.threshold = 0.8
-    trainer = vts.DataParallelTrainer(model, lr=1e-3)
+    trainer = vts.DataParallelTrainer(model, lr=1e-3, exact_loss=a.exact_loss)
     torch.manual_seed(4321 + rank)              # rank-offset noise streams
     x, y = synth_windows(a.batch, a.T, a.C, rank, dev)
     if a.model == "mixture3":

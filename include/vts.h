@@ -221,6 +221,23 @@ int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const flo
                        const float* grad_out, float threshold, float* drecon, float* dklpart,
                        int64_t nklpart, float* dpi, int64_t B, int64_t fs, vts_stream_t stream);
 
+/* Data-parallel exact loss.  Every loss above is a mean over rows, and the mixtures' masked terms are means over
+ * the rows of a class (mixture-vae-DE.py:119), so the mean of per-rank losses differs from the loss of the
+ * concatenated batch whenever ranks hold different numbers of such rows.  vts_elbo_sums writes this rank's additive
+ * statistics (sums[8]: six partial sums, the row count, one spare; KL slots from the latent tensors or, when klpart is
+ * given, from vts_reparam_kl_fwd's partial sums); the caller adds them up over ranks (one all-reduce of 8 floats);
+ * vts_elbo_from_sums forms the loss of the whole batch and this rank's backward state from the totals, for use
+ * with vts_elbo_bwd / vts_elbo_recon_bwd.  n_ranks = the number of ranks, whose gradients the caller AVERAGES
+ * afterwards: per-row gradient coefficients are multiplied by it, d loss / d pi_params (a whole-batch quantity every
+ * rank holds in full) is not.  No counterpart in the reference (single process); with one rank the result is
+ * identical to vts_elbo_fwd. */
+int vts_elbo_sums(int family, const float* recon, const float* y, const float* mean, const float* logvar,
+                  const float* scale, const float* shape, const float* klpart, int64_t nklpart, float threshold,
+                  float* sums, void* workspace, size_t workspace_bytes, int64_t B, int64_t fs, int64_t L,
+                  vts_stream_t stream);
+int vts_elbo_from_sums(int family, const float* sums, const float* pi, float beta, float n_ranks, float* state,
+                       int64_t fs, int64_t L, vts_stream_t stream);
+
 /* ---- Transformer encoder layer pieces: nn.TransformerEncoderLayer(d_model, nhead, dropout=0.2) ----
  * mixture-vae-transformer.py:39-40,49.  A layer is: packed in-projection (vts_linear_fwd) -> vts_mha_fwd ->
  * out-projection -> vts_dropout_add_fwd -> vts_layernorm_fwd -> vts_linear_relu_dropout_fwd -> vts_linear_fwd

@@ -294,20 +294,42 @@ __global__ __launch_bounds__(256) void elbo_partials_kernel(
 //   2: c_norm  3: c_klg (multiplies d/dx of sum(1+lv-mu^2-e^lv))  4: c_klp
 //   5: c_ext (kind 3: extra coefficient of (recon-y) on the rows with |y| > thr)
 // klpart / nkl: optional [nkl][2] partial sums of slots 3 and 4 produced by reparam_kl_fwd_kernel.
+// Data-parallel form: with sums_out the six sums (and the row count, slot 6) are written out instead of the
+// loss, to be added up over ranks by the caller; with sums_in the loss is formed from such totals (B = the
+// total row count they carry, nrec / B = fs, nlat / B = L) and every per-row gradient coefficient is
+// multiplied by gscale = the number of ranks, whose gradients the caller averages afterwards.
 __global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, int nparts,
                                      const float* __restrict__ klpart, int nkl, const float* __restrict__ pi,
-                                     float beta, long B, long nrec, long nlat, float* __restrict__ out) {
+                                     float beta, long B, long nrec, long nlat, float* __restrict__ out,
+                                     const float* __restrict__ sums_in, float* __restrict__ sums_out, float gscale) {
   __shared__ float smem[24];
   float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int p = threadIdx.x; p < nparts; p += blockDim.x)
+  if (sums_in == nullptr) {
+    for (int p = threadIdx.x; p < nparts; p += blockDim.x)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) s[i] += part[(long)p * 6 + i];
-  for (int p = threadIdx.x; p < nkl; p += blockDim.x) {
-    s[3] += klpart[2 * p];
-    s[4] += klpart[2 * p + 1];
+      for (int i = 0; i < 6; ++i) s[i] += part[(long)p * 6 + i];
+    for (int p = threadIdx.x; p < nkl; p += blockDim.x) {
+      s[3] += klpart[2 * p];
+      s[4] += klpart[2 * p + 1];
+    }
+    block_sum<6>(s, smem);
   }
-  block_sum<6>(s, smem);
   if (threadIdx.x != 0) return;
+  if (sums_out != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sums_out[i] = s[i];
+    sums_out[6] = (float)B;
+    sums_out[7] = 0.f;
+    return;
+  }
+  if (sums_in != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = sums_in[i];
+    const long rows = (long)sums_in[6];
+    nrec = rows * (nrec / B);
+    nlat = rows * (nlat / B);
+    B = rows;
+  }
   const float R = s[0] / (float)nrec;
   const float klg = -0.5f * s[3] / (float)B;
   const float klp = s[4] / (float)nlat;
@@ -358,8 +380,9 @@ __global__ void elbo_finalize_kernel(int kind, const float* __restrict__ part, i
     dpi0 = p0 * (Ag - sg);
     dpi1 = p1 * (Ap - sg);
   }
-  out[0] = loss; out[1] = c_all; out[2] = c_norm; out[3] = c_klg; out[4] = c_klp;
-  out[5] = c_ext; out[6] = 0.f; out[7] = 0.f; out[8] = dpi0; out[9] = dpi1;
+  out[0] = loss; out[1] = c_all * gscale; out[2] = c_norm * gscale; out[3] = c_klg * gscale; out[4] = c_klp * gscale;
+  // d loss / d pi_params is a whole-batch quantity that every rank holds in full: averaging leaves it as it is
+  out[5] = c_ext * gscale; out[6] = 0.f; out[7] = 0.f; out[8] = dpi0; out[9] = dpi1;
 }
 
 // Elementwise ELBO gradients scaled by the upstream scalar *gout (or 1 when gout == nullptr).
@@ -724,7 +747,7 @@ int vts_ew_elbo_fwd(int kind, const float* recon, const float* y, const float* m
                      shape, thr, nrec, nlat, part);
   VTS_CHECK_LAUNCH("elbo_partials");
   hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, (const float*)nullptr, 0,
-                     pi, beta, B, nrec, nlat, out10);
+                     pi, beta, B, nrec, nlat, out10, (const float*)nullptr, (float*)nullptr, 1.f);
   VTS_CHECK_LAUNCH("elbo_finalize");
   return VTS_OK;
 }
@@ -805,8 +828,32 @@ int vts_ew_elbo_recon_fwd(int kind, const float* recon, const float* y, const fl
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, thr, nrec, 0L, part);
   VTS_CHECK_LAUNCH("elbo_partials");
   hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, klpart, nkl, pi, beta, B,
-                     nrec, nlat, out10);
+                     nrec, nlat, out10, (const float*)nullptr, (float*)nullptr, 1.f);
   VTS_CHECK_LAUNCH("elbo_finalize");
+  return VTS_OK;
+}
+
+// This rank's additive statistics of the loss: sums[0..5] as elbo_partials_kernel's slots, sums[6] = rows.
+// The KL slots come from the latent tensors, or from klpart (reparam_kl_fwd's partial sums) when given.
+int vts_ew_elbo_sums(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                     const float* scale, const float* shape, const float* klpart, int nkl, float thr, long B, int fs,
+                     int L, float* part, float* sums, hipStream_t st) {
+  const long nrec = B * fs, nlat = klpart ? 0L : B * L;
+  const int blocks = vts_ew_elbo_blocks(nrec, nlat);
+  hipLaunchKernelGGL(elbo_partials_kernel, dim3(blocks), dim3(256), 0, st, kind, recon, y, mean, logvar, scale, shape,
+                     thr, nrec, nlat, part);
+  VTS_CHECK_LAUNCH("elbo_partials");
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, klpart, klpart ? nkl : 0,
+                     (const float*)nullptr, 0.f, B, nrec, B * L, (float*)nullptr, (const float*)nullptr, sums, 1.f);
+  VTS_CHECK_LAUNCH("elbo_sums");
+  return VTS_OK;
+}
+
+int vts_ew_elbo_from_sums(int kind, const float* sums, const float* pi, float beta, float gscale, int fs, int L,
+                          float* out10, hipStream_t st) {
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(64), 0, st, kind, (const float*)nullptr, 0,
+                     (const float*)nullptr, 0, pi, beta, 1L, (long)fs, (long)L, out10, sums, (float*)nullptr, gscale);
+  VTS_CHECK_LAUNCH("elbo_from_sums");
   return VTS_OK;
 }
 

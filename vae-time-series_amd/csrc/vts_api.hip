@@ -8,6 +8,11 @@
 // ---- internal entry points (gemm_f32.hip, lstm_rec_f32.hip, elementwise.hip) -------------------
 int vts_ew_adam_counted(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                         long long* state, float gscale, hipStream_t st);
+int vts_ew_elbo_sums(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                     const float* scale, const float* shape, const float* klpart, int nkl, float thr, long B, int fs,
+                     int L, float* part, float* sums, hipStream_t st);
+int vts_ew_elbo_from_sums(int kind, const float* sums, const float* pi, float beta, float gscale, int fs, int L,
+                          float* out10, hipStream_t st);
 int vts_gemm_pick_ksplit(int M, int N, long K, int mode);
 size_t vts_gemm_slab_bytes(int M, int N, int ksplit);
 int vts_gemm_inproj(const float* X, const float* W, const float* b0, const float* b1, float* G, int Bwin, int T,
@@ -510,6 +515,32 @@ int vts_elbo_recon_fwd(int family, const float* recon, const float* y, const flo
   VTS_REQUIRE(workspace_bytes >= vts_elbo_workspace_bytes(B, fs, L), "elbo_recon_fwd: workspace too small");
   return vts_ew_elbo_recon_fwd(family, recon, y, klpart, (int)nklpart, pi, threshold, beta, B, (int)fs, (int)L,
                                reinterpret_cast<float*>(workspace), state, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_elbo_sums(int family, const float* recon, const float* y, const float* mean, const float* logvar,
+                  const float* scale, const float* shape, const float* klpart, int64_t nklpart, float threshold,
+                  float* sums, void* workspace, size_t workspace_bytes, int64_t B, int64_t fs, int64_t L,
+                  vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 3 && recon && y && sums && workspace && B > 0 && fs > 0 && L > 0,
+              "elbo_sums: bad arguments");
+  if (klpart) {
+    VTS_REQUIRE(family <= 2 && nklpart == vts_reparam_kl_blocks(B, L), "elbo_sums: nklpart is not vts_reparam_kl_blocks(B, L)");
+  } else {
+    VTS_REQUIRE(family == VTS_GPD || (mean && logvar), "elbo_sums: gaussian inputs missing");
+    VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape), "elbo_sums: gpd inputs missing");
+  }
+  VTS_REQUIRE(B < (1 << 24), "elbo_sums: the row count travels as a float (B < 2^24)");
+  VTS_REQUIRE(workspace_bytes >= vts_elbo_workspace_bytes(B, fs, L), "elbo_sums: workspace too small");
+  return vts_ew_elbo_sums(family, recon, y, mean, logvar, scale, shape, klpart, (int)nklpart, threshold, B, (int)fs,
+                          (int)L, reinterpret_cast<float*>(workspace), sums, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_elbo_from_sums(int family, const float* sums, const float* pi, float beta, float n_ranks, float* state,
+                       int64_t fs, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 3 && sums && state && fs > 0 && L > 0, "elbo_from_sums: bad arguments");
+  VTS_REQUIRE(family < VTS_MIXTURE || pi, "elbo_from_sums: mixture needs pi");
+  return vts_ew_elbo_from_sums(family, sums, pi, beta, n_ranks, (int)fs, (int)L, state,
+                               reinterpret_cast<hipStream_t>(stream));
 }
 
 int vts_elbo_recon_bwd(int family, const float* recon, const float* y, const float* state, const float* grad_out,

@@ -5,7 +5,7 @@ sites.  All arithmetic runs in the HIP library; torch supplies device memory, st
 torch.distributed.  Importing works without a GPU; calling any op without one raises.
 """
 from . import _lib
-from .functional import get_mode, set_mode
+from .functional import get_mode, set_mode, set_loss_reduction
 from .functional import (gaussian_elbo, gpd_elbo, layer_norm, linear, lstm, mixture_elbo,
                          reparameterize_gaussian, reparameterize_gpd, reparameterize_mixture,
                          mixture_split_elbo, multi_head_attention, dropout_add, dropout_mask,
@@ -21,6 +21,6 @@ __all__ = [
     "lstm", "linear", "layer_norm", "reparameterize_gaussian", "reparameterize_gpd",
     "reparameterize_mixture", "gaussian_elbo", "gpd_elbo", "mixture_elbo", "mixture_split_elbo",
     "multi_head_attention", "dropout_add", "dropout_mask", "TransformerEncoderLayer", "TransformerMixtureVAE",
-    "set_mode", "get_mode", "Adam", "FlatParameters", "train_step", "GraphedTrainStep", "DataParallelTrainer", "shard_batch",
+    "set_mode", "get_mode", "set_loss_reduction", "Adam", "FlatParameters", "train_step", "GraphedTrainStep", "DataParallelTrainer", "shard_batch",
     "WindowSource", "create_sliding_windows", "ThreeComponentVAE", "reparameterize_mixture3", "mixture3_elbo",
 ]

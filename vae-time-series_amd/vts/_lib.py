@@ -59,6 +59,8 @@ SIGNATURES = {
     "vts_elbo_recon_fwd": (_int, [_int, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64,
                                   _ptr]),
     "vts_elbo_recon_bwd": (_int, [_int, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _ptr, _i64, _ptr, _i64, _i64, _ptr]),
+    "vts_elbo_sums": (_int, [_int] + [_ptr] * 7 + [_i64, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64, _ptr]),
+    "vts_elbo_from_sums": (_int, [_int, _ptr, _ptr, _f32, _f32, _ptr, _i64, _i64, _ptr]),
     "vts_linear_relu_dropout_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _u64, _int, _ptr]),
     "vts_ffn_hidden_bytes": (_sz, [_i64, _i64]),
     "vts_ffn_mask_bytes": (_sz, [_i64, _i64]),

@@ -438,6 +438,37 @@ def reparameterize_mixture(mean, logvar, scale, shape, pi_params, choice=None, e
 
 
 # ------------------------------------------------------------------------------------- ELBO
+# Data-parallel exact loss: when set, the ELBO functions form the loss of the concatenated batch of all ranks.
+# (reduce, ranks): reduce(sums) adds the 8-float statistics up over ranks in place (an all-reduce on the current
+# stream); ranks = the number of ranks, whose gradients the caller averages afterwards.
+_loss_reduction = None
+
+
+def set_loss_reduction(reduce=None, scale: float = 1.0) -> None:
+    """``reduce=None`` restores per-rank losses (the mean of which equals the global loss only when every
+    rank holds the same number of rows of each masked class)."""
+    global _loss_reduction
+    _loss_reduction = None if reduce is None else (reduce, float(scale))
+
+
+def _elbo_state_global(lib, family, recon, y, mean, logvar, scale, shape, klpart, pi, threshold, beta, B, fs, Ld):
+    """state of the loss over all ranks' rows: local sums -> reduce -> finalize."""
+    reduce, gscale = _loss_reduction
+    dev = recon.device
+    sums = torch.empty(8, device=dev, dtype=torch.float32)
+    state = torch.empty(16, device=dev, dtype=torch.float32)
+    ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
+    ws = L.workspace(ws_bytes, dev)
+    nkl = 0 if klpart is None else klpart.shape[0]
+    L.check(L.timer.call("elbo_sums", lib.vts_elbo_sums, family, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar),
+                         L.ptr(scale), L.ptr(shape), L.ptr(klpart), nkl, threshold, L.ptr(sums), L.wptr(ws), ws_bytes,
+                         B, fs, Ld, L.stream()), "vts_elbo_sums")
+    reduce(sums)
+    L.check(L.timer.call("elbo_from_sums", lib.vts_elbo_from_sums, family, L.ptr(sums), L.ptr(pi), beta, gscale,
+                         L.ptr(state), fs, Ld, L.stream()), "vts_elbo_from_sums")
+    return state
+
+
 class _Elbo(torch.autograd.Function):
     @staticmethod
     def forward(ctx, family: int, recon, y, mean, logvar, scale, shape, pi, threshold: float, beta: float):
@@ -449,10 +480,13 @@ class _Elbo(torch.autograd.Function):
         ref = mean if mean is not None else scale
         Ld = ref.shape[1]
         mean, logvar, scale, shape, pi = [_c(t) for t in (mean, logvar, scale, shape, pi)]
-        state = torch.empty(16, device=recon.device, dtype=torch.float32)
-        ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
-        ws = L.workspace(ws_bytes, recon.device)
-        L.check(L.timer.call("elbo_fwd", lib.vts_elbo_fwd, family, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale),
+        if _loss_reduction is not None:
+            state = _elbo_state_global(lib, family, recon, y, mean, logvar, scale, shape, None, pi, threshold, beta, B, fs, Ld)
+        else:
+            state = torch.empty(16, device=recon.device, dtype=torch.float32)
+            ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
+            ws = L.workspace(ws_bytes, recon.device)
+            L.check(L.timer.call("elbo_fwd", lib.vts_elbo_fwd, family, L.ptr(recon), L.ptr(y), L.ptr(mean), L.ptr(logvar), L.ptr(scale),
                                  L.ptr(shape), L.ptr(pi), threshold, beta, L.ptr(state), L.wptr(ws), ws_bytes, B, fs,
                                  Ld, L.stream()), "vts_elbo_fwd")
         ctx.family, ctx.threshold, ctx.dims = family, threshold, (B, fs, Ld)
@@ -494,12 +528,15 @@ class _ElboRecon(torch.autograd.Function):
         recon, y, klpart, pi = recon.contiguous(), y.contiguous(), klpart.contiguous(), _c(pi)
         B = recon.shape[0]
         fs = recon.numel() // B
-        state = torch.empty(16, device=recon.device, dtype=torch.float32)
-        ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
-        ws = L.workspace(ws_bytes, recon.device)
-        L.check(L.timer.call("elbo_recon_fwd", lib.vts_elbo_recon_fwd, family, L.ptr(recon), L.ptr(y),
-                             L.ptr(klpart), klpart.shape[0], L.ptr(pi), threshold, beta, L.ptr(state), L.wptr(ws),
-                             ws_bytes, B, fs, Ld, L.stream()), "vts_elbo_recon_fwd")
+        if _loss_reduction is not None:
+            state = _elbo_state_global(lib, family, recon, y, None, None, None, None, klpart, pi, threshold, beta, B, fs, Ld)
+        else:
+            state = torch.empty(16, device=recon.device, dtype=torch.float32)
+            ws_bytes = lib.vts_elbo_workspace_bytes(B, fs, Ld)
+            ws = L.workspace(ws_bytes, recon.device)
+            L.check(L.timer.call("elbo_recon_fwd", lib.vts_elbo_recon_fwd, family, L.ptr(recon), L.ptr(y),
+                                 L.ptr(klpart), klpart.shape[0], L.ptr(pi), threshold, beta, L.ptr(state), L.wptr(ws),
+                                 ws_bytes, B, fs, Ld, L.stream()), "vts_elbo_recon_fwd")
         ctx.family, ctx.threshold, ctx.dims = family, threshold, (B, fs, klpart.shape[0])
         ctx.save_for_backward(recon, y, state)
         return state[0]

@@ -54,11 +54,15 @@ class DataParallelTrainer:
     scaling folded into the update kernel."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-3, group: Optional[dist.ProcessGroup] = None,
-                 max_buckets: int = 3, optimizer_factory=None):
+                 max_buckets: int = 3, optimizer_factory=None, exact_loss: bool = False):
         self.model = model
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
+        # exact_loss: the ELBO of the concatenated batch (one extra all-reduce of 8 floats in the forward pass)
+        # instead of the mean of per-rank losses; they differ only through the mixtures' masked means, when
+        # ranks hold different numbers of rows of a class.  The three-component loss keeps per-rank counts.
+        self.exact_loss = bool(exact_loss) and self.distributed     # also with a 1-rank group: same code path
         self.flat = FlatParameters(model)
         self.opt = (optimizer_factory or (lambda flat: Adam(flat, lr=lr)))(self.flat)
         self.buckets = plan_buckets(self.flat, max_buckets)
@@ -88,7 +92,15 @@ class DataParallelTrainer:
         self.opt.zero_grad()
         self._remaining = list(self._counts)
         self._pending = []
-        loss = forward_loss(self.model, x, y, noise)
+        if self.exact_loss:
+            from . import functional as F
+            F.set_loss_reduction(lambda sums: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group), self.world)
+            try:
+                loss = forward_loss(self.model, x, y, noise)
+            finally:
+                F.set_loss_reduction(None)
+        else:
+            loss = forward_loss(self.model, x, y, noise)
         loss.backward()
         if self.distributed:
             # parameters that received no gradient this step never fire their hook
@@ -105,7 +117,7 @@ class DataParallelTrainer:
 
     def global_loss(self, loss: torch.Tensor) -> torch.Tensor:
         """Mean of the per-rank losses (equal shards)."""
-        if self.world == 1:
+        if self.world == 1 or self.exact_loss:    # exact_loss: the loss already is the whole batch's
             return loss
         out = loss.clone()
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
