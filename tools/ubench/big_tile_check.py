@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vae-time-series_amd"))
 import torch
 from vts import _lib as L
+if os.environ.get("VTS_LIB"): L.LIB_PATH = os.path.abspath(os.environ["VTS_LIB"])
 lib = L.load()
 dev = torch.device("cuda:0")
 B, T, H = int(os.environ.get("B", 4096)), 96, 256
