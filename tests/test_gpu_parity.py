@@ -143,6 +143,8 @@ def test_clamped_shape_gets_zero_gradient(golden):
     (48, 9, 20, 256, 3),     # headline hidden size
     (64, 6, 8, 256, 2),      # batch splits into 32-window pairs: the paired recurrent kernels (bf16x3)
     (96, 5, 12, 128, 1),     # paired kernels at hidden 128, three pairs
+    (128, 6, 8, 256, 2),     # one cluster of eight workgroups: the W_hh-stationary forward recurrence (bf16x3)
+    (384, 9, 4, 256, 1),     # three clusters
     (512, 64, 12, 64, 2),    # 32768 window rows: weight gradients take the split-K plan of the 256 x 128 tile kernel (bf16x3)
 ])
 @pytest.mark.parametrize("mode", MODES, indirect=True)

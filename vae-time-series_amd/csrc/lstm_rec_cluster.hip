@@ -1,0 +1,348 @@
+// Forward LSTM recurrence, bf16x3, with W_hh stationary: eight workgroups (eight CUs) share 128 windows.
+//
+// The one-workgroup-per-16-windows kernels (lstm_rec_bf16x3.hip) re-read the whole packed W_hh image from the
+// XCD's L2 every time step, and that stream - not the matrix cores - sets their step time.  Here member c of a
+// cluster owns hidden units [32c, 32c + 32) for all four gates: its slice of W_hh (128 gate columns x 256 k, hi
+// and lo planes, 128 KiB) stays in LDS for the whole sequence, and what crosses the L2 each step is h instead:
+// every member publishes its 128 x 32 slice of h_t (bf16 hi / lo, A-fragment order, 16 KiB) and reads all of
+// h_t (128 KiB) for the next step.
+//
+// Hand-off: payload fragments are stored and loaded with sc1 buffer accesses (they go around the CU's L1, which
+// would otherwise keep the lines of two steps ago: the two exchange buffers alternate with the step's parity);
+// every storing wave drains its stores (vmcnt(0)) before the workgroup barrier behind which one lane raises the
+// member's flag; one wave of each consumer polls the eight flags, the others wait at a barrier it joins.
+// A member reuses a buffer only after it has seen every peer publish the step in between, so no peer can
+// still be reading it.  Every poll is bounded: if a peer never shows up (the launcher only takes this kernel
+// when the whole grid fits on the device at one workgroup per CU) the kernels leave with an error word set and
+// NaN in the last step of the h sequence and in the final states, which turns the step's loss into NaN.
+#include "lstm_rec_common.h"
+
+namespace {
+
+constexpr int CH = 256;                 // hidden size this kernel is built for
+constexpr int NC = 8;                   // members per cluster
+constexpr int CROWS = 128;              // windows per cluster
+constexpr int CT = 8;                   // column tiles per member: 4 gates x 2 hidden tiles
+constexpr int KS = CH / 32;             // k-steps of the recurrent product
+constexpr int W_LDS = KS * 2 * CT * 1024;            // resident slice: [ks][hi | lo][ct][64 lanes] x 16 B = 128 KiB
+constexpr int S_PLANE = CROWS * 64;                  // staging plane: 128 rows x 32 bf16
+constexpr int C_LDS = W_LDS + 2 * S_PLANE;           // 144 KiB
+constexpr int X_PLANE = 8 * KS * 1024;               // exchange plane: [row tile 8][ks 8][64 lanes] x 16 B = 64 KiB
+constexpr size_t X_CLUSTER = 2ul * 2 * X_PLANE;      // [parity][hi | lo] = 256 KiB per cluster
+constexpr int FLAG_STRIDE = 32;                      // uint32 words between flags (one 128-byte line each)
+
+__device__ __forceinline__ bf16x8 frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+// image for this kernel: [member c][ks][hi | lo][ct = gate*2 + jl][lane] ->
+//   W_hh[gate*H + (2c + jl)*16 + (lane & 15)][32*ks + 8*(lane >> 4) + e],  e = 0..7
+__global__ void pack_whh3c_kernel(const float* __restrict__ W, u32x4* __restrict__ out) {
+  const int total = CH * CH;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int ct = rest & 7; rest >>= 3;
+    const int p = rest & 1; rest >>= 1;
+    const int ks = rest & 7;
+    const int c = rest >> 3;
+    const int gate = ct >> 1, jl = ct & 1;
+    const int row = gate * CH + (2 * c + jl) * 16 + (lane & 15);
+    const int k0 = 32 * ks + 8 * (lane >> 4);
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hi, lo;
+      split2(W[row * CH + k0 + 2 * q], W[row * CH + k0 + 2 * q + 1], hi, lo);
+      o[q] = p ? lo : hi;
+    }
+    out[idx] = o;
+  }
+}
+
+typedef unsigned long long u64;
+typedef unsigned bvec4 __attribute__((vector_size(16)));
+// xchg: [cluster][parity][plane][rt][ks][lane] 16-byte fragments; flags: [cluster][member] words FLAG_STRIDE
+// apart, zero before the launch, flag = number of steps published; err: one word, set on a poll timeout.
+__global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
+    float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
+    float* __restrict__ clast, const u32x4* __restrict__ Wp, u64* __restrict__ xchg, unsigned* __restrict__ flags,
+    unsigned* __restrict__ err, int T, int nclusters) {
+  constexpr int JT = CH / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemc[];
+  __shared__ int dead;
+  u32x4* wl = reinterpret_cast<u32x4*>(smemc);                 // [ks][plane][ct][lane]
+  unsigned char* stage = smemc + W_LDS;                        // [plane][128 rows][64 B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  // the eight members of a cluster have equal blockIdx.x % 8: one XCD under round-robin dispatch (speed only)
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int c = j & 7;
+  const int q = (j >> 3) * 8 + xcd;
+  if (q >= nclusters) return;
+  if (tid == 0) dead = 0;
+
+  // resident slice of the image
+  {
+    const u32x4* src = Wp + (size_t)c * (W_LDS / 16);
+#pragma unroll 4
+    for (int i = tid; i < W_LDS / 16; i += 256) wl[i] = src[i];
+  }
+  // the cluster's exchange buffers as a buffer resource: 16-byte accesses with the sc1 bit (aux 16), which go
+  // around the CU's L1 like the agent-scope atomics the flags use, and which the compiler's wait counting sees
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(xchg + (size_t)q * (X_CLUSTER / 8), 0, (int)X_CLUSTER, 0x00020000);
+  unsigned* fq = flags + (size_t)q * NC * FLAG_STRIDE;
+
+  f32x4 cst[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl) cst[mt][jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // gate block (tile16) of batch tile bt, step t, column tile (gate, hidden tile jt)
+  auto gblock = [&](int mt, int t, int gate, int jl) -> long {
+    const long bt = (long)q * 8 + 2 * wave + mt;
+    return ((bt * T + t) * (4 * JT) + gate * JT + 2 * c + jl) * 256 + lane * 4;
+  };
+  f32x4 gnext[2][CT];
+  auto load_g = [&](int t) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) gnext[mt][ct] = ld_stream(G + gblock(mt, t, ct >> 1, ct & 1));
+  };
+  auto load_g_part = [&](int t, int part) {      // blocks 2*part, 2*part + 1 of the sixteen
+#pragma unroll
+    for (int i = 2 * part; i < 2 * part + 2; ++i) gnext[i >> 3][i & 7] = ld_stream(G + gblock(i >> 3, t, (i & 7) >> 1, i & 1));
+  };
+  load_g(0);
+  __syncthreads();   // image slice and `dead` in place
+
+#ifdef VTS_C_STAMP
+  long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#define STAMP(i) do { const long long now = clock64(); stamp[i] += now - tprev; tprev = now; } while (0)
+#else
+#define STAMP(i)
+#endif
+  for (int t = 0; t < T; ++t) {
+    STAMP(6);
+    // Order of a step, chosen so that only the hand-off itself sits on the critical path:
+    //   wait for h_{t-1} -> issue ALL its fragment loads -> only then the next step's gate prefetch (loads
+    //   return in order: a prefetch issued first would sit in front of every wait for a fragment) ->
+    //   product -> cell update -> publish h_t and raise the flag -> only then the step's bulk stores
+    //   (gates, cells, h sequence: HBM writes that drain under the next step's wait and product).
+    u32x4 a[KS][2][2];   // [ks][mt][plane]
+    if (t > 0) {
+#ifndef VTS_C_NOSYNC
+      if (wave == 0) {
+        int spins = 0;
+        bool ok = false;
+        do {
+          const unsigned seen = lane < NC ? __hip_atomic_load(fq + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0xffffffffu;
+          ok = __all(seen >= (unsigned)t);
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(1);
+        } while (++spins < (1 << 21));
+        if (!ok && lane == 0) {
+          dead = 1;
+          atomicOr(err, 1u);
+        }
+      }
+      __syncthreads();
+      if (dead) break;
+#endif
+      STAMP(0);
+    }
+    const int xin_off = ((t + 1) & 1) * (2 * X_PLANE);      // buffer of h_{t-1}
+    auto load_a = [&](int ks) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int off = xin_off + p * X_PLANE + ((2 * wave + mt) * KS + ks) * 1024 + lane * 16;
+          a[ks][mt][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 16));
+        }
+    };
+    if (t > 0) {
+      STAMP(0);
+      load_a(0);
+      load_a(1);
+    }
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = gnext[mt][ct];
+    STAMP(1);
+
+    if (t == 0 && T > 1) load_g(1);
+#ifndef VTS_C_NOPROD
+    if (t > 0) {
+      // 64 groups of six MFMAs, one per (k-step, column tile); the W fragments of a group are read from LDS two
+      // groups ahead (an LDS read takes about as long as one group), in a three-slot register rotation
+      u32x4 bh[3], bl[3];
+      auto fetch_b = [&](int idx, int slot) {
+        bh[slot] = wl[(((idx >> 3) * 2 + 0) * CT + (idx & 7)) * 64 + lane];
+        bl[slot] = wl[(((idx >> 3) * 2 + 1) * CT + (idx & 7)) * 64 + lane];
+      };
+      fetch_b(0, 0);
+      fetch_b(1, 1);
+#pragma unroll
+      for (int idx = 0; idx < KS * CT; ++idx) {
+        const int ks = idx >> 3, ct = idx & 7, slot = idx % 3;
+        if (idx + 2 < KS * CT) fetch_b(idx + 2, (idx + 2) % 3);
+        if (ct == 0) {
+          // memory instructions of the step are spread over the product: the fragments two k-steps ahead and
+          // two blocks of the next step's gate prefetch per k-step (their issue waits on the store queue)
+          if (ks + 2 < KS) load_a(ks + 2);
+          if (t + 1 < T) load_g_part(t + 1, ks);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][mt][1]), frag(bh[slot]), acc[mt][ct], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][mt][0]), frag(bl[slot]), acc[mt][ct], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][mt][0]), frag(bh[slot]), acc[mt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#endif
+
+    STAMP(2);
+    // cell update, lane-local: acc[mt][gate*2 + jl][reg] is gate `gate` of window row 4g + reg of batch tile mt,
+    // hidden unit (2c + jl)*16 + r.  The activations go back into acc, h into hv, for the stores further down.
+    f32x4 hv[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float gi = fast_sigmoid(acc[mt][0 + jl][reg]);
+          const float gf = fast_sigmoid(acc[mt][2 + jl][reg]);
+          const float gg = fast_tanh(acc[mt][4 + jl][reg]);
+          const float go = fast_sigmoid(acc[mt][6 + jl][reg]);
+          acc[mt][0 + jl][reg] = gi; acc[mt][2 + jl][reg] = gf; acc[mt][4 + jl][reg] = gg; acc[mt][6 + jl][reg] = go;
+          cst[mt][jl][reg] = gf * cst[mt][jl][reg] + gi * gg;
+          const float h = go * fast_tanh(cst[mt][jl][reg]);
+          hv[mt][jl][reg] = h;
+          // h -> staging as bf16 hi / lo pairs: the even lane of a pair writes the two hi halves, the odd one the lo halves
+          const float other = lane_xor1(h);
+          const bool odd = r & 1;
+          unsigned hi, lo;
+          split2(odd ? other : h, odd ? h : other, hi, lo);
+          const int row = (2 * wave + mt) * 16 + 4 * g + reg;
+          const int col = jl * 16 + (r & ~1);
+          *reinterpret_cast<unsigned*>(stage + (odd ? S_PLANE : 0) + row * 64 + col * 2) = odd ? lo : hi;
+        }
+    STAMP(3);
+    if (t + 1 < T) {
+      lds_barrier();                      // the staging tile is complete
+      // publish this member's k-step (ks = c) of h_t: [plane][rt][lane] fragments, 1 KiB per wave instruction
+      const int xout_off = (t & 1) * (2 * X_PLANE);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;    // [plane 2][rt 8][lane 64]
+        const int p = idx >> 9, rt = (idx >> 6) & 7, l = idx & 63;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + p * S_PLANE + (rt * 16 + (l & 15)) * 64 + (l >> 4) * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, v), xrsrc,
+                                               xout_off + p * X_PLANE + (rt * KS + c) * 1024 + l * 16, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fq + c * FLAG_STRIDE, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    STAMP(4);
+    // bulk stores of the step
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const long bt = (long)q * 8 + 2 * wave + mt;
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int jt = 2 * c + jl;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const long b = bt * 16 + 4 * g + reg;
+          hseq[(b * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
+          if (t == T - 1) {
+            if (hlast != nullptr) hlast[b * CH + jt * 16 + r] = hv[mt][jl][reg];
+            if (clast != nullptr) clast[b * CH + jt * 16 + r] = cst[mt][jl][reg];
+          }
+        }
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) st_stream(G + gblock(mt, t, gate, jl), acc[mt][gate * 2 + jl]);
+        st_stream(cseq + ((bt * T + t) * JT + jt) * 256 + lane * 4, cst[mt][jl]);
+      }
+    }
+    STAMP(5);
+  }
+  if (dead) {
+    // a peer never published: besides the error word, poison what the layers above read (last step of the h
+    // sequence, final states), so that the loss of such a step is NaN instead of a plausible number
+    const float poison = __builtin_nanf("");
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const long b = ((long)q * 8 + 2 * wave + mt) * 16 + 4 * g + reg;
+          const int col = (2 * c + jl) * 16 + r;
+          hseq[(b * T + T - 1) * CH + col] = poison;
+          if (hlast != nullptr) hlast[b * CH + col] = poison;
+          if (clast != nullptr) clast[b * CH + col] = poison;
+        }
+  }
+#ifdef VTS_C_STAMP
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 7; ++i) reinterpret_cast<long long*>(err + 2)[i] = stamp[i];
+#endif
+}
+
+}  // namespace
+
+// The cluster kernel serves the bench-sized launches: hidden 256, whole clusters, and a grid that is resident
+// at once at one workgroup per CU (its members wait for each other).
+bool vts_lstm_rec3c_usable(int B, int T, int H) {
+  if (H != CH || B < CROWS || (B % CROWS) != 0 || T < 2) return false;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  const int nclusters = B / CROWS;
+  return 64 * vts_cdiv(nclusters, 8) <= cus;
+}
+
+// xws: exchange buffers (X_CLUSTER bytes per cluster) followed by the flags; fws: flag words + error word.
+size_t vts_lstm_rec3c_xchg_bytes(int B) { return (size_t)(B / CROWS) * X_CLUSTER; }
+size_t vts_lstm_rec3c_flag_bytes(int B) { return ((size_t)(B / CROWS) * NC + 1) * FLAG_STRIDE * sizeof(unsigned); }
+
+int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
+                       void* xws, void* fws, int B, int T, hipStream_t stream) {
+  const int nclusters = B / CROWS;
+  u32x4* img = reinterpret_cast<u32x4*>(Wp);
+  hipLaunchKernelGGL(pack_whh3c_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img);
+  VTS_CHECK_LAUNCH("pack_whh3c");
+  unsigned* flags = reinterpret_cast<unsigned*>(fws);
+  unsigned* err = flags + (size_t)nclusters * NC * FLAG_STRIDE;
+  if (hipMemsetAsync(flags, 0, vts_lstm_rec3c_flag_bytes(B), stream) != hipSuccess) {
+    vts_set_error("lstm_rec3c_fwd: clearing the hand-off flags failed");
+    return VTS_ERR_HIP;
+  }
+  static unsigned long long lds_done = 0;
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), C_LDS, &lds_done, "lstm_rec3c_fwd"))
+    return rc;
+  hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(64 * vts_cdiv(nclusters, 8)), dim3(256), C_LDS, stream, G, cseq, hseq,
+                     hlast, clast, img, reinterpret_cast<unsigned long long*>(xws), flags, err, T, nclusters);
+  VTS_CHECK_LAUNCH("lstm_rec3c_fwd");
+  return VTS_OK;
+}

@@ -4,6 +4,7 @@
 #include "../../include/vts.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 // ---- internal entry points (gemm_f32.hip, lstm_rec_f32.hip, elementwise.hip) -------------------
 int vts_ew_adam_counted(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
@@ -46,6 +47,9 @@ int vts_attn_dropout_add(const float* residual, const float* x, const unsigned c
 int vts_attn_dropout_mask(unsigned long long seed, float drop_p, unsigned char* keep, long n, hipStream_t st);
 bool vts_lstm_hidden_supported(int H);
 bool vts_lstm_rec3_supported(int H);
+bool vts_lstm_rec3c_usable(int B, int T, int H);
+int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
+                       void* xws, void* fws, int B, int T, hipStream_t stream);
 int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
                       float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream);
 int vts_lstm_rec3_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
@@ -195,6 +199,17 @@ int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_las
               "lstm_recurrent_fwd: gates, cells, hseq, h_last and workspace must be 16-byte aligned");
   VTS_REQUIRE(workspace_bytes >= vts_lstm_recurrent_workspace_bytes(B, T, H),
               "lstm_recurrent_fwd: workspace %zu B too small", workspace_bytes);
+  // bench-sized bf16x3 launches: W_hh stationary in clusters of eight workgroups.  Its exchange buffers and flags
+  // live in the parts of the workspace that only the backward pass uses (gradient seeds, bias partials), which
+  // are exactly large enough: 2 KiB and 256 B per window against 2 KiB and ~8 B needed.
+  static const bool cluster_on = [] { const char* e = getenv("VTS_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
+  if (dtype_mode == 1 && cluster_on && vts_lstm_rec3c_usable((int)B, (int)T, (int)H)) {
+    char* ws = reinterpret_cast<char*>(workspace);
+    char* fws = ws + rec_ws_pack_bytes(H);
+    char* xws = fws + rec_ws_dbpart_bytes(B, H);
+    return vts_lstm_rec3c_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), xws, fws,
+                              (int)B, (int)T, reinterpret_cast<hipStream_t>(stream));
+  }
   // bf16x3 recurrence for the hidden sizes it is built for; smaller ones stay on the fp32 kernel
   if (dtype_mode == 1 && vts_lstm_rec3_supported((int)H))
     return vts_lstm_rec3_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), (int)B,
