@@ -20,8 +20,8 @@ torch.cuda.synchronize()
 off = (4 * H * H * 4 + 255) // 256 * 256 + (B // 128) * 8 * 32 * 4
 raw = ws[off:off + 128].cpu()
 print("err word", raw[:4].view(torch.int32).item())
-st = raw[8:64].view(torch.int64).tolist()
-names = ["poll + barrier", "issue h loads + gate prefetch", "product", "cell update", "publish + drain + barrier + flag", "bulk stores", "loop top"]
+st = raw[8:72].view(torch.int64).tolist()
+names = ["poll + barrier", "issue h loads", "product", "cell update", "publish + drain + barrier + flag", "issue bulk stores", "loop top", "acc = prefetched gates (wait)"]
 tot = sum(st)
 for n, v in zip(names, st):
     print(f"{n:36s} {v / T:9.0f} ticks/step  {100 * v / tot:5.1f} %")

@@ -16,6 +16,8 @@
 // when the whole grid fits on the device at one workgroup per CU) the kernels leave with an error word set and
 // NaN in the last step of the h sequence and in the final states, which turns the step's loss into NaN.
 #include "lstm_rec_common.h"
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -31,6 +33,18 @@ constexpr int X_PLANE = 8 * KS * 1024;               // exchange plane: [row til
 constexpr size_t X_CLUSTER = 2ul * 2 * X_PLANE;      // [parity][hi | lo] = 256 KiB per cluster
 constexpr int FLAG_STRIDE = 32;                      // uint32 words between flags (one 128-byte line each)
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), unrolled by the front end (the optimiser's own
+// full-unroll budget is smaller than the 64 MFMA groups of a step, and their register rotation needs static indices)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// Bulk tile16 stores are plain ones here: no image in the L2 needs protecting from them (the one-workgroup kernels
+// write them non-temporally for that), and plain stores measured 3 % faster per step.
+__device__ __forceinline__ void st_bulk(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ bf16x8 frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 __device__ __forceinline__ float lane_xor1(float v) {
@@ -123,8 +137,48 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
   load_g(0);
   __syncthreads();   // image slice and `dead` in place
 
+  // bulk stores of step t (gates, cells, h sequence: HBM writes), from the registers the cell update left them in
+  f32x4 act[2][CT];
+  f32x4 hv[2][2];
+  // one sixteenth of the same: sub = mt*8 + jl*4 + {0: h sequence rows, 1: gates i f, 2: gates g o, 3: cell block}
+  auto store_part = [&](int t, int sub) {
+    const int mt = sub >> 3, jl = (sub >> 2) & 1, what = sub & 3;
+    const long bt = (long)q * 8 + 2 * wave + mt;
+    const int jt = 2 * c + jl;
+    if (what == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) hseq[((bt * 16 + 4 * g + reg) * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
+    } else if (what == 3) {
+      st_bulk(cseq + ((bt * T + t) * JT + jt) * 256 + lane * 4, cst[mt][jl]);
+    } else {
+#pragma unroll
+      for (int gate = 2 * (what - 1); gate < 2 * what; ++gate) st_bulk(G + gblock(mt, t, gate, jl), act[mt][gate * 2 + jl]);
+    }
+  };
+  auto bulk_store = [&](int t) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const long bt = (long)q * 8 + 2 * wave + mt;
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const int jt = 2 * c + jl;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const long b = bt * 16 + 4 * g + reg;
+          hseq[(b * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
+          if (t == T - 1) {
+            if (hlast != nullptr) hlast[b * CH + jt * 16 + r] = hv[mt][jl][reg];
+            if (clast != nullptr) clast[b * CH + jt * 16 + r] = cst[mt][jl][reg];
+          }
+        }
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) st_bulk(G + gblock(mt, t, gate, jl), act[mt][gate * 2 + jl]);
+        st_bulk(cseq + ((bt * T + t) * JT + jt) * 256 + lane * 4, cst[mt][jl]);
+      }
+    }
+  };
 #ifdef VTS_C_STAMP
-  long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+  long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
 #define STAMP(i) do { const long long now = clock64(); stamp[i] += now - tprev; tprev = now; } while (0)
 #else
@@ -132,12 +186,12 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 #endif
   for (int t = 0; t < T; ++t) {
     STAMP(6);
-    // Order of a step, chosen so that only the hand-off itself sits on the critical path:
-    //   wait for h_{t-1} -> issue ALL its fragment loads -> only then the next step's gate prefetch (loads
-    //   return in order: a prefetch issued first would sit in front of every wait for a fragment) ->
-    //   product -> cell update -> publish h_t and raise the flag -> only then the step's bulk stores
-    //   (gates, cells, h sequence: HBM writes that drain under the next step's wait and product).
-    u32x4 a[KS][2][2];   // [ks][mt][plane]
+    // Order of a step, chosen so that only the hand-off itself sits on the critical path (vector memory
+    // instructions complete in issue order, so whatever is issued before a load delays it):
+    //   wait for h_{t-1} -> issue the fragment loads of its first two k-steps -> product, with the other
+    //   fragment loads, the next step's gate prefetch and the bulk stores of step t-1 spread over it ->
+    //   cell update -> publish h_t and raise the flag.
+    u32x4 a[3][2][2];    // [ks % 3][mt][plane]: fragments of three k-steps in flight
     if (t > 0) {
 #ifndef VTS_C_NOSYNC
       if (wave == 0) {
@@ -167,20 +221,21 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const int off = xin_off + p * X_PLANE + ((2 * wave + mt) * KS + ks) * 1024 + lane * 16;
-          a[ks][mt][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 16));
+          a[ks % 3][mt][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 16));
         }
     };
     if (t > 0) {
       STAMP(0);
       load_a(0);
       load_a(1);
+      STAMP(1);
     }
     f32x4 acc[2][CT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = gnext[mt][ct];
-    STAMP(1);
+    STAMP(7);
 
     if (t == 0 && T > 1) load_g(1);
 #ifndef VTS_C_NOPROD
@@ -188,40 +243,46 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
       // 64 groups of six MFMAs, one per (k-step, column tile); the W fragments of a group are read from LDS two
       // groups ahead (an LDS read takes about as long as one group), in a three-slot register rotation
       u32x4 bh[3], bl[3];
+      const int tnext = min(t + 1, T - 1);
       auto fetch_b = [&](int idx, int slot) {
         bh[slot] = wl[(((idx >> 3) * 2 + 0) * CT + (idx & 7)) * 64 + lane];
         bl[slot] = wl[(((idx >> 3) * 2 + 1) * CT + (idx & 7)) * 64 + lane];
       };
       fetch_b(0, 0);
       fetch_b(1, 1);
-#pragma unroll
-      for (int idx = 0; idx < KS * CT; ++idx) {
-        const int ks = idx >> 3, ct = idx & 7, slot = idx % 3;
+      static_for<KS * CT>([&](auto idx_c) {
+        constexpr int idx = decltype(idx_c)::value;
+        constexpr int ks = idx >> 3, ct = idx & 7, slot = idx % 3;
         if (idx + 2 < KS * CT) fetch_b(idx + 2, (idx + 2) % 3);
         if (ct == 0) {
-          // memory instructions of the step are spread over the product: the fragments two k-steps ahead and
-          // two blocks of the next step's gate prefetch per k-step (their issue waits on the store queue)
           if (ks + 2 < KS) load_a(ks + 2);
-          if (t + 1 < T) load_g_part(t + 1, ks);
         }
+        // The CU's one vector-memory pipe moves 64 bytes a clock, and a wave stalls at a memory instruction while
+        // that pipe's queue is full.  A step moves about 300 KiB through it, against 6144 clocks of matrix work:
+        // so the memory instructions are spread over the product, one or two per group of MFMAs - the
+        // fragments two k-steps ahead, two blocks of the next step's gates and two sixteenths of the previous
+        // step's bulk stores (gates, cells, h sequence; they read act, hv and cst, which the cell update
+        // further down overwrites) per k-step.
+        if (ct == 2) load_g_part(tnext, ks);     // the last step re-reads its own blocks: no branch in the product
+        if (ct == 4) store_part(t - 1, 2 * ks);
+        if (ct == 6) store_part(t - 1, 2 * ks + 1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][mt][1]), frag(bh[slot]), acc[mt][ct], 0, 0, 0);
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks % 3][mt][1]), frag(bh[slot]), acc[mt][ct], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][mt][0]), frag(bl[slot]), acc[mt][ct], 0, 0, 0);
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks % 3][mt][0]), frag(bl[slot]), acc[mt][ct], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][mt][0]), frag(bh[slot]), acc[mt][ct], 0, 0, 0);
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks % 3][mt][0]), frag(bh[slot]), acc[mt][ct], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
     }
 #endif
 
     STAMP(2);
     // cell update, lane-local: acc[mt][gate*2 + jl][reg] is gate `gate` of window row 4g + reg of batch tile mt,
-    // hidden unit (2c + jl)*16 + r.  The activations go back into acc, h into hv, for the stores further down.
-    f32x4 hv[2][2];
+    // hidden unit (2c + jl)*16 + r.  The activations go into act, h into hv: the next step's product stores them.
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -232,7 +293,7 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
           const float gf = fast_sigmoid(acc[mt][2 + jl][reg]);
           const float gg = fast_tanh(acc[mt][4 + jl][reg]);
           const float go = fast_sigmoid(acc[mt][6 + jl][reg]);
-          acc[mt][0 + jl][reg] = gi; acc[mt][2 + jl][reg] = gf; acc[mt][4 + jl][reg] = gg; acc[mt][6 + jl][reg] = go;
+          act[mt][0 + jl][reg] = gi; act[mt][2 + jl][reg] = gf; act[mt][4 + jl][reg] = gg; act[mt][6 + jl][reg] = go;
           cst[mt][jl][reg] = gf * cst[mt][jl][reg] + gi * gg;
           const float h = go * fast_tanh(cst[mt][jl][reg]);
           hv[mt][jl][reg] = h;
@@ -263,29 +324,8 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
       if (tid == 0) __hip_atomic_store(fq + c * FLAG_STRIDE, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     STAMP(4);
-    // bulk stores of the step
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const long bt = (long)q * 8 + 2 * wave + mt;
-#pragma unroll
-      for (int jl = 0; jl < 2; ++jl) {
-        const int jt = 2 * c + jl;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const long b = bt * 16 + 4 * g + reg;
-          hseq[(b * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
-          if (t == T - 1) {
-            if (hlast != nullptr) hlast[b * CH + jt * 16 + r] = hv[mt][jl][reg];
-            if (clast != nullptr) clast[b * CH + jt * 16 + r] = cst[mt][jl][reg];
-          }
-        }
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate) st_stream(G + gblock(mt, t, gate, jl), acc[mt][gate * 2 + jl]);
-        st_stream(cseq + ((bt * T + t) * JT + jt) * 256 + lane * 4, cst[mt][jl]);
-      }
-    }
-    STAMP(5);
   }
+  if (!dead) bulk_store(T - 1);
   if (dead) {
     // a peer never published: besides the error word, poison what the layers above read (last step of the h
     // sequence, final states), so that the loss of such a step is NaN instead of a plausible number
@@ -305,7 +345,7 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
   }
 #ifdef VTS_C_STAMP
   if (blockIdx.x == 0 && tid == 0)
-    for (int i = 0; i < 7; ++i) reinterpret_cast<long long*>(err + 2)[i] = stamp[i];
+    for (int i = 0; i < 8; ++i) reinterpret_cast<long long*>(err + 2)[i] = stamp[i];
 #endif
 }
 
