@@ -146,6 +146,14 @@ def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int
 
 
 # ----------------------------------------------------------------------------------- Linear
+def _linear_mode(M: int, N: int, K: int) -> int:
+    """dtype_mode of one Linear layer.  Layers below 2 GFLOP per product (at 4096 windows: every head and decoder
+    layer of the LSTM models) always take the fp32 matrix path: they are launch-latency sized, so bf16x3 buys
+    nothing there, and its ~1e-5 systematic shortfall per product compounds along the decoder -> z -> head
+    gradient chain (4e-4 on the normal-latent heads at the bench shape, against 7e-7 in fp32)."""
+    return _MODE if 2.0 * M * N * K >= 2e9 else 0
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act: int, keep, drop_p: float = DROP_P, seed: int = 0):
@@ -165,12 +173,13 @@ class _Linear(torch.autograd.Function):
         if act == L.ACT_RELU_DROPOUT and keep is None:
             # mask from the library's counter hash: nothing but y is needed for backward
             L.check(L.timer.call(f"linear_fwd {M}x{N}x{K}", lib.vts_linear_relu_dropout_fwd, L.ptr(x), x.stride(0),
-                                 L.ptr(weight), L.ptr(_c(bias)), L.ptr(y), M, N, K, drop_p, seed, _MODE, L.stream()),
+                                 L.ptr(weight), L.ptr(_c(bias)), L.ptr(y), M, N, K, drop_p, seed, _linear_mode(M, N, K),
+                                 L.stream()),
                     "vts_linear_relu_dropout_fwd")
         else:
             L.check(L.timer.call(f"linear_fwd {M}x{N}x{K}", lib.vts_linear_fwd, L.ptr(x), x.stride(0), L.ptr(weight),
-                                 L.ptr(_c(bias)), L.ptr(y), M, N, K, act, L.ptr(keep), scale, L.ptr(aux), _MODE,
-                                 L.stream()), "vts_linear_fwd")
+                                 L.ptr(_c(bias)), L.ptr(y), M, N, K, act, L.ptr(keep), scale, L.ptr(aux),
+                                 _linear_mode(M, N, K), L.stream()), "vts_linear_fwd")
         ctx.act = act
         ctx.scale = scale
         ctx.has_bias = bias is not None
@@ -191,7 +200,7 @@ class _Linear(torch.autograd.Function):
         ws = L.workspace(ws_bytes, x.device)
         L.check(L.timer.call(f"linear_bwd {M}x{N}x{K}" + ("" if dx is not None else " nodx"), lib.vts_linear_bwd, L.ptr(dy), L.ptr(y), L.ptr(aux), ctx.act, ctx.scale,
                              L.ptr(x), x.stride(0), L.ptr(weight), L.ptr(dx), K, 0, L.ptr(dw), L.ptr(db), 0,
-                             L.wptr(ws), ws_bytes, M, N, K, _MODE, L.stream()), "vts_linear_bwd")
+                             L.wptr(ws), ws_bytes, M, N, K, _linear_mode(M, N, K), L.stream()), "vts_linear_bwd")
         return dx, dw, db, None, None, None, None
 
 
