@@ -76,7 +76,7 @@ def test_bench_sized_lstm_stack_matches_torch_cpu(mode):
 def _case(kind):
     if kind not in _CACHE:
         sd = R.init_state(kind, C, H, LD, 1, seed=0)
-        if kind == "mixture":
+        if kind in ("mixture", "gpd"):
             # keep the GPD shapes off the 1e-6 clamp, where the reference's own fp32 sampler gradient is noise
             sd["encoder.shape_layer_extreme.weight"] *= 0.25
             sd["encoder.shape_layer_extreme.bias"].fill_(0.5)
@@ -90,7 +90,7 @@ def _case(kind):
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
-@pytest.mark.parametrize("kind", ["mixture", "gaussian"])
+@pytest.mark.parametrize("kind", ["mixture", "gpd", "gaussian"])
 def test_bench_sized_step_matches_oracle(kind, mode):
     import vts
     assert torch.cuda.is_available(), "GPU tests need a ROCm device"
@@ -117,3 +117,50 @@ def test_bench_sized_step_matches_oracle(kind, mode):
         # fp32 products: no flip in this draw (the kernels are deterministic, so that does not vary between runs)
         tol = TOL if (mode == "f32" or name.startswith("decoder.out.")) else KINK_TOL
         assert rel <= tol, f"{kind}/{mode}: gradient of {name} is off by {rel:.2e} (L2-relative, bound {tol:.0e})"
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_bench_scale_transformer_step_matches_oracle(mode):
+    """The attention-encoder variant on a quarter of the bench batch (1024 windows x 96 x 370 = 98 304 tokens
+    through d_model 64, 8 heads, 2 layers, dim_ff 2048; the oracle's masks alone are 2.4 GB at this size), same
+    bounds as the LSTM models' step: its feed-forward blocks hold 400 million ReLU units."""
+    import vts
+    from oracle import ref_transformer as RT
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    dev = torch.device("cuda:0")
+    Bt, d, nhead, layers = 1024, 64, 8, 2
+    if "transformer" not in _CACHE:
+        sd = RT.init_state(C, d, layers, LD, 1, seed=3)
+        sd["encoder.shape_layer_extreme.weight"] *= 0.25
+        sd["encoder.shape_layer_extreme.bias"].fill_(0.5)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(Bt, T, C, generator=g)
+        y = torch.randn(Bt, 1, generator=g)
+        thr = float(y.abs().median())
+        noise = RT.draw_noise(Bt, T, d, nhead, layers, LD, seed=5)
+        loss, _, grads = RT.loss_and_grads(sd, x, y, noise, nhead, thr, beta=1.0)
+        _CACHE["transformer"] = (sd, x, y, thr, noise, loss, grads)
+    sd, x, y, thr, noise, loss_ref, grads_ref = _CACHE["transformer"]
+    vts.set_mode(mode)
+    try:
+        m = vts.TransformerMixtureVAE(C, d, layers, nhead, LD, 1, beta=1.0).to(dev)
+        m.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+        m.train()
+        outs = m(x.to(dev), {k: v.to(dev) for k, v in noise.items()})
+        loss = m.loss_function(outs[0], y.to(dev), *outs[1:], thr)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        vts.set_mode("f32")
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    for name, p in m.named_parameters():
+        ref = grads_ref[name]
+        if ref.abs().max() == 0:
+            assert p.grad is None or p.grad.abs().max().item() == 0, name
+            continue
+        if name == "pi_params":
+            assert (p.grad.detach().cpu() - ref).abs().max().item() <= 1e-6 * abs(loss_ref.item())
+            continue
+        rel = _l2_rel(p.grad.detach().cpu(), ref)
+        tol = TOL if (mode == "f32" or name.startswith("decoder.out.") or name.startswith("decoder.final_fcn.")) else KINK_TOL
+        assert rel <= tol, f"transformer/{mode}: gradient of {name} is off by {rel:.2e} (L2-relative, bound {tol:.0e})"

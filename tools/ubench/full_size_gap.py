@@ -9,7 +9,7 @@ from oracle import ref_torch as R
 kind = sys.argv[1] if len(sys.argv) > 1 else "mixture"
 B, T, C, H, LD = int(os.environ.get("FS_B", 4096)), 96, 370, 256, 32
 sd = R.init_state(kind, C, H, LD, 1, seed=0)
-if kind == "mixture":
+if kind in ("mixture", "gpd"):
     sd["encoder.shape_layer_extreme.weight"] *= 0.25
     sd["encoder.shape_layer_extreme.bias"].fill_(0.5)
 SEED = int(os.environ.get('FS_SEED', 11))
