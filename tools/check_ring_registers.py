@@ -48,11 +48,12 @@ def kernels(asm):
 
 def check(name, body):
     """Forward dataflow over the kernel's control-flow graph.  The state is the FIFO of
-    outstanding ring loads (register sets, oldest first).  Only ring loads are modelled: other
-    VMEM operations can only make a given vmcnt(N) stricter than the model assumes (loads return in
-    order) or, for stores, may retire early, so leaving them out is the conservative reading.  A
-    register is in flight from its ring load until an s_waitcnt vmcnt(N) leaves at most N younger
-    ring loads outstanding; any instruction touching an in-flight register is an error."""
+    outstanding vector-memory loads, oldest first: ring loads with the registers they write, every other
+    load (global / buffer / scratch / flat) as an entry without registers.  Loads return in order, so an
+    s_waitcnt vmcnt(N) leaves at most the N youngest of them outstanding.  Stores are left out: they share the
+    counter but may retire early, so counting on them would be unsound, while ignoring them only makes a
+    given vmcnt(N) stricter than the model assumes.  A register is in flight from its ring load until such a
+    wait retires it; any instruction touching an in-flight register is an error."""
     code, labels, from_asm, in_asm = [], {}, set(), False
     for l in body:
         if "#ASMSTART" in l:
@@ -70,6 +71,7 @@ def check(name, body):
         code.append(l)
     ring_re = re.compile(r"^global_load_dwordx4 ([va]\[\d+:\d+\]), v\d+, s\[\d+:\d+\]")
     is_ring = [bool(ring_re.match(l)) and i in from_asm for i, l in enumerate(code)]
+    other_load_re = re.compile(r"^(global|buffer|scratch|flat)_load")
     if not any(is_ring):
         return None                       # a kernel without an asm ring: nothing to check
 
@@ -112,6 +114,12 @@ def check(name, body):
                     seen.add(l)
                     bad.append(f"{name}: `{l}` reloads registers still in flight")
                 fifo.append(dst)
+            elif other_load_re.match(l):
+                hit = regs_of(l[len(op):]) & inflight
+                if hit and report and l not in seen:
+                    seen.add(l)
+                    bad.append(f"{name}: `{l}` touches in-flight ring registers {sorted(hit)[:8]}")
+                fifo.append(set())
             elif op == "s_waitcnt":
                 w = re.search(r"vmcnt\((\d+)\)", l)
                 if w:

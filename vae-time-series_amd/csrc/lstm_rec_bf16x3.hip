@@ -419,11 +419,12 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
       return *reinterpret_cast<const u32x4*>(da_s + plane * PLANE + r * ROWB + (((4 * ks + g) ^ r) << 4));
     };
     u32x4 ah = lds_a(0, 0), al = lds_a(1, 0);
-    // one k-step: fragments w[0..JPW) = hi, w[JPW..2*JPW) = lo of this wave's JPW output tiles
-    auto kstep = [&](u32x4 (&w)[UT], int ks) {
+    // one k-step: fragments w[0..JPW) = hi, w[JPW..2*JPW) = lo of this wave's JPW output tiles; `allowed` = how
+    // many younger vector-memory loads may still be outstanding when this buffer's loads have landed
+    auto kstep = [&](u32x4 (&w)[UT], int ks, auto allowed) {
       const int kn = (ks + 1) & (KS - 1);
       const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);
-      w_wait<3 * UT, UT, RING_AG>(w);
+      w_wait<decltype(allowed)::value, UT, RING_AG>(w);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int jl = 0; jl < JPW; ++jl)
@@ -438,16 +439,31 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
       ah = nh;
       al = nl;
     };
+    // In steady state three ring buffers' loads (3 * UT) are younger than the one being waited for.  The first
+    // three k-steps of a product are different: the step's 4 * JPW = 2 * UT gate loads (load_step above, always
+    // issued; loads return in order) also sit between the ring loads issued before the cell backward and the
+    // ones issued here, so 5 * UT loads may stay outstanding.  Waiting for 3 * UT there would drain the gate
+    // loads - a whole HBM latency - and the cell backward's stores before the product's first MFMA.
+    constexpr std::integral_constant<int, 3 * UT> steady{};
+    constexpr std::integral_constant<int, 5 * UT> first{};
+    w_issue<UT, RING_AG>(w3, ks_ptr(3), voff);
+    kstep(w0, 0, first);
+    w_issue<UT, RING_AG>(w0, ks_ptr(4 & (KS - 1)), voff);
+    kstep(w1, 1, first);
+    w_issue<UT, RING_AG>(w1, ks_ptr(5 & (KS - 1)), voff);
+    kstep(w2, 2, first);
+    w_issue<UT, RING_AG>(w2, ks_ptr(6 & (KS - 1)), voff);
+    kstep(w3, 3, steady);
 #pragma unroll 1
-    for (int ks = 0; ks < KS; ks += 4) {
+    for (int ks = 4; ks < KS; ks += 4) {
       w_issue<UT, RING_AG>(w3, ks_ptr(ks + 3), voff);
-      kstep(w0, ks);
+      kstep(w0, ks, steady);
       w_issue<UT, RING_AG>(w0, ks_ptr((ks + 4) & (KS - 1)), voff);
-      kstep(w1, ks + 1);
+      kstep(w1, ks + 1, steady);
       w_issue<UT, RING_AG>(w1, ks_ptr((ks + 5) & (KS - 1)), voff);
-      kstep(w2, ks + 2);
+      kstep(w2, ks + 2, steady);
       w_issue<UT, RING_AG>(w2, ks_ptr((ks + 6) & (KS - 1)), voff);
-      kstep(w3, ks + 3);
+      kstep(w3, ks + 3, steady);
     }
 #pragma unroll
     for (int jl = 0; jl < JPW; ++jl) dh[jl] = acc[jl];
