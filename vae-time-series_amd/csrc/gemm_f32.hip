@@ -1252,22 +1252,48 @@ int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int
 }
 
 // dW[4H][F] = sum over window rows m' of dG[m'][:]^T . X[window row(m', tshift)][:F]
-int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
-                       int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream) {
+// columns [0, F) of a weight gradient whose rows are ldc apart; X points at the first of these columns
+static int wgrad_t16_cols(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T, int F,
+                          long ldx, long ldc, int N4H, int tshift, int accumulate, int mode, hipStream_t stream) {
   GemmParams P{};
   P.mode = mode;
   const int Bp = (Bwin + 15) / 16 * 16;
   P.A = dG; P.B = X;
   P.M = N4H; P.N = F; P.K = Bp * T;
-  P.ldb = ldx; P.ldc = F;
+  P.ldb = ldx; P.ldc = ldc;
   P.b_map = 1; P.T = T; P.Bwin = Bwin; P.b_tshift = tshift;
   set_split(P, ksplit);
   P.big_split = split_plan_big(P.M, P.N, P.K, mode);
   P.C = (P.ksplit > 1) ? slabs : dW;
+  if (P.ksplit > 1) P.ldc = F;          // slabs are dense [M][F]
   P.accumulate = (P.ksplit > 1) ? 0 : accumulate;
   int rc = launch<A_T16T, B_KN, C_ROW>(P, stream);
   if (rc) return rc;
-  return finish_split(P, dW, F, accumulate, stream);
+  return finish_split(P, dW, ldc, accumulate, stream);
+}
+
+// Where the 256 x 128 plan of a weight gradient is cut in two along its columns, or 0.  That plan runs one
+// workgroup per CU, so its tile count x k-slices has to come out near the CU count with the same number of slices
+// on every XCD: 4H = 1024 rows x 256 columns is 8 tiles x 32 slices = 256 workgroups, but 370 columns are 12 tiles
+// x 16 slices = 192 (a quarter of the chip idle; 24 slices would start a second round).  Cutting at the last
+// multiple of 256 gives 8 tiles x 32 slices plus 4 tiles x 64 slices: two full launches.
+int vts_gemm_wgrad_cut(int M, int N, long K, int mode) {
+  if (!split_plan_big(M, N, K, mode) || N <= 256 || (N % 256) == 0) return 0;
+  return N / 256 * 256;
+}
+
+int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
+                       int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream) {
+  const long K = (long)((Bwin + 15) / 16 * 16) * T;
+  const int cut = vts_gemm_wgrad_cut(N4H, F, K, mode);
+  if (cut == 0)
+    return wgrad_t16_cols(dG, X, dW, slabs, ksplit, Bwin, T, F, ldx, F, N4H, tshift, accumulate, mode, stream);
+  // the two launches run one after the other on the stream and share the slab buffer
+  int rc = wgrad_t16_cols(dG, X, dW, slabs, vts_gemm_pick_ksplit(N4H, cut, K, mode), Bwin, T, cut, ldx, F, N4H, tshift,
+                          accumulate, mode, stream);
+  if (rc) return rc;
+  return wgrad_t16_cols(dG, X + cut, dW + cut, slabs, vts_gemm_pick_ksplit(N4H, F - cut, K, mode), Bwin, T, F - cut, ldx,
+                        F, N4H, tshift, accumulate, mode, stream);
 }
 
 // Y[M][N] = act(X[M][K] . W[N][K]^T + bias)

@@ -22,6 +22,7 @@ int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int
                        int accumulate, int mode, hipStream_t stream);
 int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
                        int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream);
+int vts_gemm_wgrad_cut(int M, int N, long K, int mode);
 int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
                         int N, int K, int act, const float* keep, float keep_scale, unsigned long long drop_seed,
                         unsigned drop_thresh, float* aux, unsigned long long* bits_out, int mode,
@@ -159,8 +160,20 @@ size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
   return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H);
 }
 size_t vts_lstm_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t F, int64_t H) {
-  const int ks = vts_gemm_pick_ksplit((int)(4 * H), (int)F, pad16(B) * T, 0);   // mode 0 splits the most
-  return round256(vts_gemm_slab_bytes((int)(4 * H), (int)F, ks)) + 256;
+  const int M = (int)(4 * H);
+  const long K = pad16(B) * T;
+  size_t need = 0;
+  // either arithmetic mode may be asked for with this workspace; the bf16x3 plan may cut the columns in two
+  for (int mode = 0; mode < 2; ++mode) {
+    const int cut = vts_gemm_wgrad_cut(M, (int)F, K, mode);
+    const int parts[2] = {cut ? cut : (int)F, cut ? (int)F - cut : 0};
+    for (int n : parts)
+      if (n > 0) {
+        const size_t b = vts_gemm_slab_bytes(M, n, vts_gemm_pick_ksplit(M, n, K, mode));
+        need = b > need ? b : need;
+      }
+  }
+  return round256(need) + 256;
 }
 size_t vts_lstm_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H) {
   const size_t w1 = vts_lstm_wgrad_workspace_bytes(B, T, Cin, H), w2 = vts_lstm_wgrad_workspace_bytes(B, T, H, H);
