@@ -90,6 +90,9 @@ def lstm_flops(kind, B, T, C, H):
         if k > 0:
             per.setdefault("lstm_dgrad", []).append(inproj)
             total += inproj
+            # both weight gradients of such a layer may run as one launch (vts_lstm_wgrad_pair): same FLOPs,
+            # already counted above under the two separate names
+            per.setdefault("lstm_wgrad_pair", []).append(inproj + rec)
     return per, total
 
 
@@ -112,6 +115,7 @@ def lstm_hbm_bytes(kind, B, T, C, H):
             per.setdefault(name, []).append(b)
         if k > 0:
             per.setdefault("lstm_dgrad", []).append(gates + cells)
+            per.setdefault("lstm_wgrad_pair", []).append(gates + xin + hs)
     return per
 
 

@@ -115,6 +115,17 @@ int vts_lstm_wgrad(const float* dgates, const float* x, int tshift, float* dw, i
                    void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t F, int64_t H,
                    int dtype_mode, vts_stream_t stream);
 
+/* Both weight gradients of a layer in one launch, for the shapes it is planned for (vts_lstm_wgrad_pair_supported
+ * != 0: bf16x3 mode, F = H = 256, a contraction long enough for the 256 x 128 split-K kernel):
+ * dw_ih[4H,F] (+)= dgates^T x (tshift 0) and dw_hh[4H,H] (+)= dgates^T hseq (tshift -1), dgates read by one
+ * launch.  Same results as two vts_lstm_wgrad calls up to the order of the fp32 partial sums; same workspace
+ * (vts_lstm_wgrad_workspace_bytes(B, T, F, H)).  Other shapes: VTS_ERR_UNSUPPORTED.
+ * (autograd of nn.LSTM in the reference: vae-models/mixture-vae-DE.py:45,60,161) */
+int vts_lstm_wgrad_pair_supported(int64_t B, int64_t T, int64_t F, int64_t H, int dtype_mode);
+int vts_lstm_wgrad_pair(const float* dgates, const float* x, const float* hseq, float* dw_ih, float* dw_hh,
+                        int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
+                        int64_t F, int64_t H, int dtype_mode, vts_stream_t stream);
+
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,
                        vts_stream_t stream);

@@ -70,6 +70,13 @@ struct GemmParams {
   int kchunk;          // K elements per split (multiple of 32)
   int mode;            // 0 = f32 MFMA, 1 = bf16x3 split on the bf16 MFMA
   int big_split;       // split-K plan made for the 256 x 128 tile kernel
+  // Two products over the same A in one launch of the 256 x 128 kernel (both weight gradients of an LSTM layer):
+  // column tiles below n_cut (a multiple of 128) are product 1 = (B, ldb, b_tshift, N1 columns, slabs at C),
+  // the others product 2 = (B2, ldb2, b_tshift2, N2 columns, slabs at C2); N = n_cut + N2.  n_cut 0 = off.
+  const float* B2;
+  float* C2;
+  long ldb2;
+  int b_tshift2, N1, N2, n_cut;
 };
 
 __device__ __forceinline__ long window_row(int m, int T, int Bwin, int tshift, bool& valid) {
@@ -942,7 +949,7 @@ constexpr size_t GEMM3B_LDS_BYTES = 2ul * STAGE_B;
 static_assert(GEMM3B_LDS_BYTES >= 8 * 16 * 68 * sizeof(float), "row-major epilogue stages 8 x [16][68] floats in LDS");
 
 template <int AK, int BKIND, int CK, bool PLAIN>
-__global__ __launch_bounds__(512, 2) void gemm_bf16x3_big_kernel(const GemmParams P) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_big_kernel(const GemmParams Pin) {
   extern __shared__ __attribute__((aligned(16))) char lds3[];   // [stage][A hi | A lo | B hi | B lo]
   constexpr int OA = OpKindA<AK>::v, OB = OpKindB<BKIND>::v;
   const int tid = threadIdx.x;
@@ -954,7 +961,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_big_kernel(const GemmParam
   const int r = lane & 15, g = lane >> 4;
 
   int m0, n0, zslice, kbeg, kend;
-  if (!map_workgroup<BMB>(P, m0, n0, zslice, kbeg, kend)) return;
+  if (!map_workgroup<BMB>(Pin, m0, n0, zslice, kbeg, kend)) return;
+  // a paired launch: this workgroup's column tile belongs to one of the two products
+  GemmParams P = Pin;
+  if (Pin.n_cut > 0) {
+    if (n0 >= Pin.n_cut) {
+      P.B = Pin.B2; P.ldb = Pin.ldb2; P.b_tshift = Pin.b_tshift2; P.C = Pin.C2; P.N = Pin.N2;
+      n0 -= Pin.n_cut;
+    } else {
+      P.N = Pin.N1;
+    }
+  }
   const int ma = m0 + half * 128;                    // first A row this half stages
 
   f32x4 acc[4][4];
@@ -1294,6 +1311,44 @@ int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs,
   if (rc) return rc;
   return wgrad_t16_cols(dG, X + cut, dW + cut, slabs, vts_gemm_pick_ksplit(N4H, F - cut, K, mode), Bwin, T, F - cut, ldx,
                         F, N4H, tshift, accumulate, mode, stream);
+}
+
+// Both weight gradients of a layer whose input is H wide, dW_ih = dG^T . X and dW_hh = dG^T . Hprev (the h
+// sequence one step back), as one launch of the 256 x 128 kernel: 16 column tiles x 16 k-slices instead of twice
+// 8 x 32, i.e. k loops twice as long per workgroup, half the slab traffic and dG read by one launch.
+bool vts_gemm_wgrad_pair_usable(int N4H, int F, int Hh, long K, int mode) {
+  return mode == 1 && F == 256 && Hh == 256 && split_plan_big(N4H, F + Hh, K, mode);
+}
+size_t vts_gemm_wgrad_pair_slab_bytes(int N4H, int F, int Hh, long K, int mode) {
+  return vts_gemm_slab_bytes(N4H, F + Hh, vts_gemm_pick_ksplit(N4H, F + Hh, K, mode));
+}
+int vts_gemm_wgrad_pair_t16(const float* dG, const float* X, long ldx, const float* Hs, float* dWih, float* dWhh,
+                            float* slabs, int Bwin, int T, int F, int Hh, int N4H, int accumulate, int mode,
+                            hipStream_t stream) {
+  GemmParams P{};
+  P.mode = mode;
+  const int Bp = (Bwin + 15) / 16 * 16;
+  P.A = dG; P.B = X; P.B2 = Hs;
+  P.M = N4H; P.K = Bp * T;
+  P.N1 = F; P.N2 = Hh; P.n_cut = (F + BN - 1) / BN * BN; P.N = P.n_cut + Hh;
+  P.ldb = ldx; P.ldb2 = Hh;
+  P.b_map = 1; P.T = T; P.Bwin = Bwin; P.b_tshift = 0; P.b_tshift2 = -1;
+  set_split(P, vts_gemm_pick_ksplit(N4H, F + Hh, P.K, mode));
+  if (P.ksplit <= 1) {
+    vts_set_error("gemm: the paired weight gradient needs a split-K plan");
+    return VTS_ERR_ARG;
+  }
+  P.big_split = 1;
+  P.C = slabs;
+  P.C2 = slabs + (size_t)P.ksplit * N4H * F;
+  int rc = launch<A_T16T, B_KN, C_ROW>(P, stream);
+  if (rc) return rc;
+  GemmParams R = P;
+  R.N = F;
+  rc = finish_split(R, dWih, F, accumulate, stream);
+  if (rc) return rc;
+  R.C = P.C2; R.N = Hh;
+  return finish_split(R, dWhh, Hh, accumulate, stream);
 }
 
 // Y[M][N] = act(X[M][K] . W[N][K]^T + bias)

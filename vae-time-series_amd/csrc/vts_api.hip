@@ -23,6 +23,11 @@ int vts_gemm_dgrad_t16(const float* dG, const float* W, float* dX, int Bwin, int
 int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs, int ksplit, int Bwin, int T,
                        int F, long ldx, int N4H, int tshift, int accumulate, int mode, hipStream_t stream);
 int vts_gemm_wgrad_cut(int M, int N, long K, int mode);
+bool vts_gemm_wgrad_pair_usable(int N4H, int F, int Hh, long K, int mode);
+size_t vts_gemm_wgrad_pair_slab_bytes(int N4H, int F, int Hh, long K, int mode);
+int vts_gemm_wgrad_pair_t16(const float* dG, const float* X, long ldx, const float* Hs, float* dWih, float* dWhh,
+                            float* slabs, int Bwin, int T, int F, int Hh, int N4H, int accumulate, int mode,
+                            hipStream_t stream);
 int vts_gemm_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy, int M,
                         int N, int K, int act, const float* keep, float keep_scale, unsigned long long drop_seed,
                         unsigned drop_thresh, float* aux, unsigned long long* bits_out, int mode,
@@ -173,6 +178,10 @@ size_t vts_lstm_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t F, int64_t H
         need = b > need ? b : need;
       }
   }
+  if (vts_gemm_wgrad_pair_usable(M, (int)F, (int)H, K, 1)) {
+    const size_t b = vts_gemm_wgrad_pair_slab_bytes(M, (int)F, (int)H, K, 1);
+    need = b > need ? b : need;
+  }
   return round256(need) + 256;
 }
 size_t vts_lstm_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H) {
@@ -289,6 +298,31 @@ int vts_lstm_wgrad(const float* dgates, const float* x, int tshift, float* dw, i
                             (int)(4 * H), tshift, accumulate, dtype_mode, reinterpret_cast<hipStream_t>(stream));
 }
 
+int vts_lstm_wgrad_pair_supported(int64_t B, int64_t T, int64_t F, int64_t H, int dtype_mode) {
+  static const bool pair_on = [] { const char* e = getenv("VTS_LSTM_WGRAD_PAIR"); return !(e && e[0] == '0'); }();
+  if (!pair_on || B <= 0 || T <= 0 || !fits_int(pad16(B) * T) || !fits_int(4 * H) || !fits_int(F)) return 0;
+  return vts_gemm_wgrad_pair_usable((int)(4 * H), (int)F, (int)H, pad16(B) * T, dtype_mode) ? 1 : 0;
+}
+
+int vts_lstm_wgrad_pair(const float* dgates, const float* x, const float* hseq, float* dw_ih, float* dw_hh,
+                        int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t F,
+                        int64_t H, int dtype_mode, vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_RC(lstm_check(B, T, F, H));
+  VTS_REQUIRE(dgates && x && hseq && dw_ih && dw_hh && workspace, "lstm_wgrad_pair: null pointer");
+  VTS_REQUIRE(vts_aligned16(dgates) && vts_aligned16(workspace), "lstm_wgrad_pair: 16-byte alignment");
+  if (!vts_lstm_wgrad_pair_supported(B, T, F, H, dtype_mode)) {
+    vts_set_error("lstm_wgrad_pair: not planned for B %ld, T %ld, F %ld, H %ld, mode %d (see "
+                  "vts_lstm_wgrad_pair_supported)", (long)B, (long)T, (long)F, (long)H, dtype_mode);
+    return VTS_ERR_UNSUPPORTED;
+  }
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_wgrad_workspace_bytes(B, T, F, H),
+              "lstm_wgrad_pair: workspace %zu B too small", workspace_bytes);
+  return vts_gemm_wgrad_pair_t16(dgates, x, F, hseq, dw_ih, dw_hh, reinterpret_cast<float*>(workspace), (int)B, (int)T,
+                                 (int)F, (int)H, (int)(4 * H), accumulate, dtype_mode,
+                                 reinterpret_cast<hipStream_t>(stream));
+}
+
 int vts_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                        float* gates, float* cells, float* hseq, float* h_last, float* c_last, void* workspace,
                        size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode,
@@ -314,6 +348,8 @@ int vts_lstm_layer_bwd(const float* x, const float* hseq, const float* w_ih, con
   VTS_RC(vts_lstm_recurrent_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, w_hh, db_ih, db_hh, accumulate, workspace,
                                 workspace_bytes, B, T, H, dtype_mode, stream));
   if (dx_t16) VTS_RC(vts_lstm_dgrad(gates, w_ih, dx_t16, B, T, Cin, H, dtype_mode, stream));
+  if (dw_ih && dw_hh && vts_lstm_wgrad_pair_supported(B, T, Cin, H, dtype_mode))
+    return vts_lstm_wgrad_pair(gates, x, hseq, dw_ih, dw_hh, accumulate, wg_ws, wg_bytes, B, T, Cin, H, dtype_mode, stream);
   if (dw_ih) VTS_RC(vts_lstm_wgrad(gates, x, 0, dw_ih, accumulate, wg_ws, wg_bytes, B, T, Cin, H, dtype_mode, stream));
   if (dw_hh) VTS_RC(vts_lstm_wgrad(gates, hseq, -1, dw_hh, accumulate, wg_ws, wg_bytes, B, T, H, H, dtype_mode, stream));
   return VTS_OK;

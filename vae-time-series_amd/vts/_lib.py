@@ -39,6 +39,8 @@ SIGNATURES = {
     "vts_lstm_recurrent_bwd": (_int, [_ptr] * 8 + [_int, _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_dgrad": (_int, [_ptr] * 3 + [_i64, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_wgrad": (_int, [_ptr, _ptr, _int, _ptr, _int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_wgrad_pair_supported": (_int, [_i64, _i64, _i64, _i64, _int]),
+    "vts_lstm_wgrad_pair": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
     "vts_tile16_convert": (_int, [_ptr, _ptr, _i64, _i64, _i64, _int, _ptr]),
     "vts_linear_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _f32, _ptr, _int, _ptr]),
     "vts_linear_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -124,10 +124,16 @@ class _LSTMStack(torch.autograd.Function):
             wg_bytes = max(lib.vts_lstm_wgrad_workspace_bytes(B, T, cin, H),
                            lib.vts_lstm_wgrad_workspace_bytes(B, T, H, H))
             wg = L.workspace(wg_bytes, dev)
-            L.check(L.timer.call("lstm_wgrad_ih", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(inp), 0, L.ptr(dw_ih), 0,
-                                 L.wptr(wg), wg_bytes, B, T, cin, H, _MODE, st), "vts_lstm_wgrad")
-            L.check(L.timer.call("lstm_wgrad_hh", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw_hh),
-                                 0, L.wptr(wg), wg_bytes, B, T, H, H, _MODE, st), "vts_lstm_wgrad")
+            if lib.vts_lstm_wgrad_pair_supported(B, T, cin, H, _MODE):
+                # both weight gradients in one launch (layers whose input is another layer's h sequence)
+                L.check(L.timer.call("lstm_wgrad_pair", lib.vts_lstm_wgrad_pair, L.wptr(gates), L.ptr(inp), L.ptr(hseq),
+                                     L.ptr(dw_ih), L.ptr(dw_hh), 0, L.wptr(wg), wg_bytes, B, T, cin, H, _MODE, st),
+                        "vts_lstm_wgrad_pair")
+            else:
+                L.check(L.timer.call("lstm_wgrad_ih", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(inp), 0, L.ptr(dw_ih), 0,
+                                     L.wptr(wg), wg_bytes, B, T, cin, H, _MODE, st), "vts_lstm_wgrad")
+                L.check(L.timer.call("lstm_wgrad_hh", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw_hh),
+                                     0, L.wptr(wg), wg_bytes, B, T, H, H, _MODE, st), "vts_lstm_wgrad")
             grads[4 * k:4 * k + 4] = [dw_ih, dw_hh, db_ih, db_hh]
             dh_seq = dx
             if k == 0:
