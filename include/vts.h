@@ -116,7 +116,8 @@ int vts_lstm_wgrad(const float* dgates, const float* x, int tshift, float* dw, i
                    int dtype_mode, vts_stream_t stream);
 
 /* Both weight gradients of a layer in one launch, for the shapes it is planned for (vts_lstm_wgrad_pair_supported
- * != 0: bf16x3 mode, F = H = 256, a contraction long enough for the 256 x 128 split-K kernel):
+ * != 0: bf16x3 mode, H = 256, F >= 256, a contraction long enough for the 256 x 128 split-K kernel; columns of x
+ * past the first 256 take a launch of their own):
  * dw_ih[4H,F] (+)= dgates^T x (tshift 0) and dw_hh[4H,H] (+)= dgates^T hseq (tshift -1), dgates read by one
  * launch.  Same results as two vts_lstm_wgrad calls up to the order of the fp32 partial sums; same workspace
  * (vts_lstm_wgrad_workspace_bytes(B, T, F, H)).  Other shapes: VTS_ERR_UNSUPPORTED.

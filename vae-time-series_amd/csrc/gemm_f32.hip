@@ -1316,39 +1316,47 @@ int vts_gemm_wgrad_t16(const float* dG, const float* X, float* dW, float* slabs,
 // Both weight gradients of a layer whose input is H wide, dW_ih = dG^T . X and dW_hh = dG^T . Hprev (the h
 // sequence one step back), as one launch of the 256 x 128 kernel: 16 column tiles x 16 k-slices instead of twice
 // 8 x 32, i.e. k loops twice as long per workgroup, half the slab traffic and dG read by one launch.
+// A wider input (the first layer's 370 channels) pairs its first 256 columns with the recurrent product and
+// sends the rest through a launch of their own (4 column tiles x 64 k-slices for 114 columns).
 bool vts_gemm_wgrad_pair_usable(int N4H, int F, int Hh, long K, int mode) {
-  return mode == 1 && F == 256 && Hh == 256 && split_plan_big(N4H, F + Hh, K, mode);
+  return mode == 1 && F >= 256 && Hh == 256 && split_plan_big(N4H, 256 + Hh, K, mode);
 }
 size_t vts_gemm_wgrad_pair_slab_bytes(int N4H, int F, int Hh, long K, int mode) {
-  return vts_gemm_slab_bytes(N4H, F + Hh, vts_gemm_pick_ksplit(N4H, F + Hh, K, mode));
+  const size_t pair = vts_gemm_slab_bytes(N4H, 256 + Hh, vts_gemm_pick_ksplit(N4H, 256 + Hh, K, mode));
+  const size_t rest = F > 256 ? vts_gemm_slab_bytes(N4H, F - 256, vts_gemm_pick_ksplit(N4H, F - 256, K, mode)) : 0;
+  return pair > rest ? pair : rest;     // the launches follow each other on the stream and share the buffer
 }
 int vts_gemm_wgrad_pair_t16(const float* dG, const float* X, long ldx, const float* Hs, float* dWih, float* dWhh,
                             float* slabs, int Bwin, int T, int F, int Hh, int N4H, int accumulate, int mode,
                             hipStream_t stream) {
+  constexpr int F1 = 256;                // columns of X in the paired launch
   GemmParams P{};
   P.mode = mode;
   const int Bp = (Bwin + 15) / 16 * 16;
   P.A = dG; P.B = X; P.B2 = Hs;
   P.M = N4H; P.K = Bp * T;
-  P.N1 = F; P.N2 = Hh; P.n_cut = (F + BN - 1) / BN * BN; P.N = P.n_cut + Hh;
+  P.N1 = F1; P.N2 = Hh; P.n_cut = F1; P.N = P.n_cut + Hh;
   P.ldb = ldx; P.ldb2 = Hh;
   P.b_map = 1; P.T = T; P.Bwin = Bwin; P.b_tshift = 0; P.b_tshift2 = -1;
-  set_split(P, vts_gemm_pick_ksplit(N4H, F + Hh, P.K, mode));
+  set_split(P, vts_gemm_pick_ksplit(N4H, F1 + Hh, P.K, mode));
   if (P.ksplit <= 1) {
     vts_set_error("gemm: the paired weight gradient needs a split-K plan");
     return VTS_ERR_ARG;
   }
   P.big_split = 1;
   P.C = slabs;
-  P.C2 = slabs + (size_t)P.ksplit * N4H * F;
+  P.C2 = slabs + (size_t)P.ksplit * N4H * F1;
   int rc = launch<A_T16T, B_KN, C_ROW>(P, stream);
   if (rc) return rc;
   GemmParams R = P;
-  R.N = F;
+  R.N = F1;
   rc = finish_split(R, dWih, F, accumulate, stream);
   if (rc) return rc;
   R.C = P.C2; R.N = Hh;
-  return finish_split(R, dWhh, Hh, accumulate, stream);
+  rc = finish_split(R, dWhh, Hh, accumulate, stream);
+  if (rc || F == F1) return rc;
+  return wgrad_t16_cols(dG, X + F1, dWih + F1, slabs, vts_gemm_pick_ksplit(N4H, F - F1, P.K, mode), Bwin, T, F - F1, ldx,
+                        F, N4H, 0, accumulate, mode, stream);
 }
 
 // Y[M][N] = act(X[M][K] . W[N][K]^T + bias)

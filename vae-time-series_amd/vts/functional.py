@@ -125,7 +125,7 @@ class _LSTMStack(torch.autograd.Function):
                            lib.vts_lstm_wgrad_workspace_bytes(B, T, H, H))
             wg = L.workspace(wg_bytes, dev)
             if lib.vts_lstm_wgrad_pair_supported(B, T, cin, H, _MODE):
-                # both weight gradients in one launch (layers whose input is another layer's h sequence)
+                # both weight gradients in one launch (the first 256 input columns ride with the recurrent product)
                 L.check(L.timer.call("lstm_wgrad_pair", lib.vts_lstm_wgrad_pair, L.wptr(gates), L.ptr(inp), L.ptr(hseq),
                                      L.ptr(dw_ih), L.ptr(dw_hh), 0, L.wptr(wg), wg_bytes, B, T, cin, H, _MODE, st),
                         "vts_lstm_wgrad_pair")
