@@ -87,12 +87,12 @@ def lstm_flops(kind, B, T, C, H):
                         ("lstm_wgrad_ih", inproj), ("lstm_wgrad_hh", rec)):
             per.setdefault(name, []).append(f)
             total += f
+        # both weight gradients of a layer may run as one entry point (vts_lstm_wgrad_pair): same FLOPs, already
+        # counted above under the two separate names
+        per.setdefault("lstm_wgrad_pair", []).append(inproj + rec)
         if k > 0:
             per.setdefault("lstm_dgrad", []).append(inproj)
             total += inproj
-            # both weight gradients of such a layer may run as one launch (vts_lstm_wgrad_pair): same FLOPs,
-            # already counted above under the two separate names
-            per.setdefault("lstm_wgrad_pair", []).append(inproj + rec)
     return per, total
 
 
@@ -113,9 +113,9 @@ def lstm_hbm_bytes(kind, B, T, C, H):
                         ("lstm_recurrent_bwd", 2 * gates + cells + (0.0 if top else cells)),
                         ("lstm_wgrad_ih", gates + xin), ("lstm_wgrad_hh", gates + hs)):
             per.setdefault(name, []).append(b)
+        per.setdefault("lstm_wgrad_pair", []).append(gates + xin + hs)
         if k > 0:
             per.setdefault("lstm_dgrad", []).append(gates + cells)
-            per.setdefault("lstm_wgrad_pair", []).append(gates + xin + hs)
     return per
 
 
@@ -512,7 +512,8 @@ def main():
         # HBM bytes per launch of the dominant kernel, from the committed PMC passes (same shape only)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
-            key = {"lstm_recurrent_bwd": "lstm_rec3_bwd_kernel<256>", "lstm_recurrent_fwd": "lstm_rec3_fwd_kernel<256>"}.get(dom)
+            key = {"lstm_recurrent_bwd": "lstm_rec3_bwd_kernel<256>", "lstm_recurrent_fwd": "lstm_rec3_fwd_kernel<256>",
+                   "lstm_wgrad_pair": "gemm_bf16x3_big_kernel<3,1,0> (paired weight gradients, 256 + 256 columns)"}.get(dom)
             if a.mode == "bf16x3" and (a.batch, a.T, a.H) == (4096, 96, 256) and key in pmc:
                 roofline["traffic"] = pmc[key]["hbm_bytes"]
                 roofline["traffic_note"] = "HBM bytes per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_hbm_traffic.json)"

@@ -74,6 +74,11 @@ def main():
         ("wgrad_hh", rec_f, lambda: lib.vts_lstm_wgrad(L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw_hh), 0, L.wptr(wg),
                                                        wg_b, B, T, H, H, MODE, st)),
     ]
+    if lib.vts_lstm_wgrad_pair_supported(B, T, H, H, MODE):
+        x2 = torch.randn(B, T, H, device=dev)       # a lower layer's h sequence as this layer's input
+        dw_ih2 = torch.empty(4 * H, H, device=dev)
+        stages.append(("wgrad_pair(H)", 2 * rec_f, lambda: lib.vts_lstm_wgrad_pair(
+            L.wptr(gates), L.ptr(x2), L.ptr(hseq), L.ptr(dw_ih2), L.ptr(dw_hh), 0, L.wptr(wg), wg_b, B, T, H, H, MODE, st)))
     for name, flops, fn in stages:
         if a.only and a.only not in name:
             # still run once so later stages see initialised inputs

@@ -1,3 +1,4 @@
+# Development aid: the bench lines, rocprofv3 kernel stats and PMC passes that profiles/ holds (run on the GPU box).
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -9,6 +10,7 @@ timeout -k 10 200 python bench.py --mode f32 --no-cpu-baseline > $O/r01_bench_mi
 timeout -k 10 200 python bench.py --model gaussian --no-cpu-baseline > $O/r01_bench_gaussian_bf16x3.json 2> $O/b_g.err
 timeout -k 10 200 python bench.py --model gpd --no-cpu-baseline > $O/r01_bench_gpd_bf16x3.json 2> $O/b_gpd.err
 timeout -k 10 200 python bench.py --model mixture3 --no-cpu-baseline > $O/r01_bench_mixture3_bf16x3.json 2> $O/b_m3.err
+timeout -k 10 300 python bench.py --model transformer > $O/r01_bench_transformer_bf16x3.json 2> $O/b_tr.err
 echo benches done
 rm -rf $O/prof_r01c
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r01c -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 2 > $O/r01_bench_mixture_bf16x3_under_rocprof.json 2> $O/prof_r01c.err
