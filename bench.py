@@ -514,9 +514,12 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
             key = {"lstm_recurrent_bwd": "lstm_rec3_bwd_kernel<256>", "lstm_recurrent_fwd": "lstm_rec3_fwd_kernel<256>",
                    "lstm_wgrad_pair": "gemm_bf16x3_big_kernel<3,1,0> (paired weight gradients, 256 + 256 columns)"}.get(dom)
-            if a.mode == "bf16x3" and (a.batch, a.T, a.H) == (4096, 96, 256) and key in pmc:
+            if (a.mode == "bf16x3" and (a.batch, a.T, a.H) == (4096, 96, 256) and key in pmc
+                    and not (dom == "lstm_wgrad_pair" and a.model == "gaussian")):
                 roofline["traffic"] = pmc[key]["hbm_bytes"]
                 roofline["traffic_note"] = "HBM bytes per launch, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_hbm_traffic.json)"
+                if dom == "lstm_wgrad_pair":
+                    roofline["traffic_note"] += "; measured on the 256 + 256-column launch of the layers above the first"
         except (OSError, KeyError, ValueError):
             pass
         # The recurrent kernels re-read the packed W_hh image (4*H*H*4 bytes, L2-resident) once per
