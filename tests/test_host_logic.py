@@ -36,6 +36,22 @@ def test_sizing_calls_do_not_need_a_gpu():
     assert lib.vts_elbo_workspace_bytes(B, 1, 32) >= 5 * 4
 
 
+def test_paired_weight_gradient_plan():
+    """Which layers get both weight gradients from one launch, and that the shared workspace covers every plan
+    (pure host logic: no launch happens for an unsupported shape)."""
+    from vts import _lib
+    lib = _lib.load()
+    assert lib.vts_lstm_wgrad_pair_supported(4096, 96, 256, 256, 1) == 1       # layers above the first
+    assert lib.vts_lstm_wgrad_pair_supported(4096, 96, 370, 256, 1) == 1       # first layer: 256 columns paired
+    assert lib.vts_lstm_wgrad_pair_supported(4096, 96, 256, 256, 0) == 0       # fp32 products keep two launches
+    assert lib.vts_lstm_wgrad_pair_supported(16, 16, 1, 64, 1) == 0            # the reference's own sizes
+    assert lib.vts_lstm_wgrad_pair_supported(4096, 96, 64, 256, 1) == 0        # narrow input
+    # slabs of the paired launch: 16 k-slices x [1024, 512] floats
+    assert lib.vts_lstm_wgrad_workspace_bytes(4096, 96, 256, 256) >= 16 * 1024 * 512 * 4
+    rc = lib.vts_lstm_wgrad_pair(None, None, None, None, None, 0, None, 0, 16, 16, 1, 64, 1, None)
+    assert rc != 0
+
+
 def test_argument_errors_are_reported_not_raised_in_c():
     from vts import _lib
     lib = _lib.load()
