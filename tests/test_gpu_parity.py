@@ -458,3 +458,30 @@ def test_large_batch_against_oracle_slice(mode):
                 assert pi_grad_close(p.grad, grads_r[k], loss_r.item())
             else:
                 assert l2_rel(p.grad, grads_r[k]) < TOL, (kind, k, l2_rel(p.grad, grads_r[k]))
+
+
+def test_cluster_recurrence_timeout_is_loud(monkeypatch):
+    """The bench-sized forward recurrence runs as clusters of eight workgroups that wait for each other with
+    bounded polls.  With one member withholding its flags (fault injection through the environment, read at every
+    call) the launch must end, and h_n must come back NaN rather than as plausible numbers."""
+    import vts
+    dev = _dev()
+    vts.set_mode("bf16x3")
+    try:
+        torch.manual_seed(0)
+        m = vts.LSTM(8, 256, 1, batch_first=True).to(dev)
+        x = torch.randn(128, 6, 8, device=dev)
+        with torch.no_grad():
+            _, (h_ok, _) = m(x)
+            torch.cuda.synchronize()
+            assert torch.isfinite(h_ok).all()
+            monkeypatch.setenv("VTS_LSTM_CLUSTER_FAULT", "3")
+            _, (h_bad, _) = m(x)
+            torch.cuda.synchronize()
+            monkeypatch.delenv("VTS_LSTM_CLUSTER_FAULT")
+            _, (h_again, _) = m(x)
+            torch.cuda.synchronize()
+        assert torch.isnan(h_bad).all(), "a missed hand-off must poison the layer's output"
+        assert torch.equal(h_again, h_ok), "the next launch starts from cleared flags"
+    finally:
+        vts.set_mode("f32")

@@ -16,6 +16,7 @@
 // when the whole grid fits on the device at one workgroup per CU) the kernels leave with an error word set and
 // NaN in the last step of the h sequence and in the final states, which turns the step's loss into NaN.
 #include "lstm_rec_common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -83,7 +84,7 @@ typedef unsigned bvec4 __attribute__((vector_size(16)));
 __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
     float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
     float* __restrict__ clast, const u32x4* __restrict__ Wp, u64* __restrict__ xchg, unsigned* __restrict__ flags,
-    unsigned* __restrict__ err, int T, int nclusters) {
+    unsigned* __restrict__ err, int T, int nclusters, int spin_limit, int mute_member) {
   constexpr int JT = CH / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smemc[];
   __shared__ int dead;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
           ok = __all(seen >= (unsigned)t);
           if (ok) break;
           __builtin_amdgcn_s_sleep(1);
-        } while (++spins < (1 << 21));
+        } while (++spins < spin_limit);
         if (!ok && lane == 0) {
           dead = 1;
           atomicOr(err, 1u);
@@ -321,7 +322,9 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(fq + c * FLAG_STRIDE, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (mute_member >= 0: fault injection for the test of the timeout path - that member never raises its flag)
+      if (tid == 0 && c != mute_member)
+        __hip_atomic_store(fq + c * FLAG_STRIDE, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     STAMP(4);
   }
@@ -381,8 +384,16 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
   static unsigned long long lds_done = 0;
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), C_LDS, &lds_done, "lstm_rec3c_fwd"))
     return rc;
+  // polls give up after about two seconds; VTS_LSTM_CLUSTER_FAULT=<member> (read at every call, tests only) makes
+  // that member withhold its flags and shortens the wait, to exercise the timeout path
+  int spin_limit = 1 << 21, mute_member = -1;
+  if (const char* e = getenv("VTS_LSTM_CLUSTER_FAULT")) {
+    mute_member = atoi(e) & (NC - 1);
+    spin_limit = 1 << 10;
+  }
   hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(64 * vts_cdiv(nclusters, 8)), dim3(256), C_LDS, stream, G, cseq, hseq,
-                     hlast, clast, img, reinterpret_cast<unsigned long long*>(xws), flags, err, T, nclusters);
+                     hlast, clast, img, reinterpret_cast<unsigned long long*>(xws), flags, err, T, nclusters, spin_limit,
+                     mute_member);
   VTS_CHECK_LAUNCH("lstm_rec3c_fwd");
   return VTS_OK;
 }
