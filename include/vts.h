@@ -202,6 +202,19 @@ int vts_elbo_bwd(int family, const float* recon, const float* y, const float* me
                  float* dscale, float* dshape, float* dpi, int64_t B, int64_t fs, int64_t L,
                  vts_stream_t stream);
 
+/* vts_elbo_fwd for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, loss
+ * and state[16] as vts_elbo_fwd (bit for bit), without the workspace: the per-block partial sums go into a
+ * 24 KiB device array that is part of the library's code object (one copy per GPU, held until the process ends).
+ * Limit: B * max(fs, L) <= vts_elbo_fwd_static_max_elements() (2^20); larger inputs return VTS_ERR_ARG.  The call
+ * allocates and frees nothing.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (different streams) race; calls on one stream, or on different GPUs, do not. */
+int64_t vts_elbo_fwd_static_max_elements(void);
+int vts_elbo_fwd_static(int family, const float* recon, const float* y, const float* mean,
+                        const float* logvar, const float* scale, const float* shape, const float* pi,
+                        float threshold, float beta, float* state, int64_t B, int64_t fs, int64_t L,
+                        vts_stream_t stream);
+
 /* ---- Sampling fused with the KL sums, and the loss built from those sums ----
  * One training step reads mean/logvar/scale/shape twice in the reference: once to sample z
  * (mixture-vae-DE.py:94-107) and once for the KL terms of the loss (:123-127).  These entry points

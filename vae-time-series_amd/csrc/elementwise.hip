@@ -4,6 +4,7 @@
 #include "vts_common.h"
 #include "vts_gpd_pow.h"
 #include <initializer_list>
+#include <mutex>
 
 namespace {
 
@@ -749,6 +750,63 @@ int vts_ew_elbo_fwd(int kind, const float* recon, const float* y, const float* m
   hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, part, blocks, (const float*)nullptr, 0,
                      pi, beta, B, nrec, nlat, out10, (const float*)nullptr, (float*)nullptr, 1.f);
   VTS_CHECK_LAUNCH("elbo_finalize");
+  return VTS_OK;
+}
+
+// ---- the same loss for callers that cannot allocate ------------------------------------------------
+// The block partials of elbo_partials_kernel go into a file-scope device array instead of a caller
+// workspace.  `scratch` is a host-side stand-in for the symbol, not a device address: each device
+// that loads the code object holds its own copy, whose address hipGetSymbolAddress returns with that
+// device current.  The address is looked up once per device and kept; every launch takes it as an
+// ordinary kernel argument.  Every call on a device shares that device's array: the partials kernel
+// rewrites every slot the finalize kernel reads, so nothing has to start at zero, but two calls
+// that overlap on one device (different streams) race on it.
+constexpr int ELBO_STATIC_MAX_BLOCKS = 1024;                       // 1024 elements per block -> 2^20 elements
+constexpr int VTS_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[ELBO_STATIC_MAX_BLOCKS * 6];   // 24 KiB per device
+static float* g_scratch_ptr[VTS_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+long vts_ew_elbo_static_max_elements() { return (long)ELBO_STATIC_MAX_BLOCKS * 1024; }
+
+int vts_ew_elbo_fwd_static(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                           const float* scale, const float* shape, const float* pi, float thr, float beta, long B,
+                           int fs, int L, float* out10, hipStream_t st) {
+  const long nrec = B * fs, nlat = B * L;
+  const long nmax = nrec > nlat ? nrec : nlat;
+  if (nmax > vts_ew_elbo_static_max_elements()) {
+    vts_set_error("elbo_fwd_static: %ld elements exceed the static scratch buffer's %ld (B * max(fs, L)); use "
+                  "vts_elbo_fwd with a caller workspace", nmax, vts_ew_elbo_static_max_elements());
+    return VTS_ERR_ARG;
+  }
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VTS_MAX_DEVICES) {
+    vts_set_error("elbo_fwd_static: no current device (or device index above %d)", VTS_MAX_DEVICES - 1);
+    return VTS_ERR_HIP;
+  }
+  float* part = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+      void* p = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || p == nullptr) {
+        vts_set_error("elbo_fwd_static: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                      hipGetErrorString(e));
+        return VTS_ERR_HIP;
+      }
+      g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    part = g_scratch_ptr[dev];
+  }
+  const int blocks = vts_ew_elbo_blocks(nrec, nlat);      // <= ELBO_STATIC_MAX_BLOCKS by the check above
+  hipLaunchKernelGGL(elbo_partials_kernel, dim3(blocks), dim3(256), 0, st, kind, recon, y, mean, logvar, scale,
+                     shape, thr, nrec, nlat, part);
+  VTS_CHECK_LAUNCH("elbo_partials(static)");
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 0, st, kind, (const float*)part, blocks,
+                     (const float*)nullptr, 0, pi, beta, B, nrec, nlat, out10, (const float*)nullptr, (float*)nullptr,
+                     1.f);
+  VTS_CHECK_LAUNCH("elbo_finalize(static)");
   return VTS_OK;
 }
 

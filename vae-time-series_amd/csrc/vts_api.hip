@@ -90,6 +90,10 @@ int vts_ew_elbo_blocks(long nrec, long nlat);
 int vts_ew_elbo_fwd(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
                     const float* scale, const float* shape, const float* pi, float thr, float beta, long B, int fs,
                     int L, float* part, float* out10, hipStream_t st);
+long vts_ew_elbo_static_max_elements();
+int vts_ew_elbo_fwd_static(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
+                           const float* scale, const float* shape, const float* pi, float thr, float beta, long B,
+                           int fs, int L, float* out10, hipStream_t st);
 int vts_ew_elbo_bwd(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
                     const float* scale, const float* shape, const float* coef, const float* gout, float thr, long B,
                     int fs, int L, float* drecon, float* dmean, float* dlogvar, float* dscale, float* dshape,
@@ -523,6 +527,21 @@ int vts_elbo_fwd(int family, const float* recon, const float* y, const float* me
   VTS_REQUIRE(workspace_bytes >= vts_elbo_workspace_bytes(B, fs, L), "elbo_fwd: workspace too small");
   return vts_ew_elbo_fwd(family, recon, y, mean, logvar, scale, shape, pi, threshold, beta, B, (int)fs, (int)L,
                          reinterpret_cast<float*>(workspace), state, reinterpret_cast<hipStream_t>(stream));
+}
+
+int64_t vts_elbo_fwd_static_max_elements(void) { return vts_ew_elbo_static_max_elements(); }
+
+int vts_elbo_fwd_static(int family, const float* recon, const float* y, const float* mean, const float* logvar,
+                        const float* scale, const float* shape, const float* pi, float threshold, float beta,
+                        float* state, int64_t B, int64_t fs, int64_t L, vts_stream_t stream) {
+  VTS_REQUIRE(family >= 0 && family <= 3 && recon && y && state && B > 0 && fs > 0 && L > 0,
+              "elbo_fwd_static: bad arguments");
+  VTS_REQUIRE(family == VTS_GPD || (mean && logvar), "elbo_fwd_static: gaussian inputs missing");
+  VTS_REQUIRE(family == VTS_GAUSSIAN || (scale && shape), "elbo_fwd_static: gpd inputs missing");
+  VTS_REQUIRE(family < VTS_MIXTURE || pi, "elbo_fwd_static: mixture needs pi");
+  VTS_REQUIRE(fits_int(fs) && fits_int(L) && B <= ((int64_t)1 << 40), "elbo_fwd_static: dimension too large");
+  return vts_ew_elbo_fwd_static(family, recon, y, mean, logvar, scale, shape, pi, threshold, beta, B, (int)fs, (int)L,
+                                state, reinterpret_cast<hipStream_t>(stream));
 }
 
 int vts_elbo_bwd(int family, const float* recon, const float* y, const float* mean, const float* logvar,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "vts_reparam_bwd": (_int, [_int] + [_ptr] * 12 + [_i64, _i64, _ptr]),
     "vts_elbo_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vts_elbo_fwd": (_int, [_int] + [_ptr] * 7 + [_f32, _f32, _ptr, _ptr, _sz, _i64, _i64, _i64, _ptr]),
+    "vts_elbo_fwd_static_max_elements": (_i64, []),
+    "vts_elbo_fwd_static": (_int, [_int] + [_ptr] * 7 + [_f32, _f32, _ptr, _i64, _i64, _i64, _ptr]),
     "vts_elbo_bwd": (_int, [_int] + [_ptr] * 8 + [_f32] + [_ptr] * 6 + [_i64, _i64, _i64, _ptr]),
     "vts_reparam_kl_blocks": (_i64, [_i64, _i64]),
     "vts_reparam_kl_fwd": (_int, [_int] + [_ptr] * 8 + [_f32, _ptr, _ptr, _i64, _i64, _ptr]),
