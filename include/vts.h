@@ -127,6 +127,46 @@ int vts_lstm_wgrad_pair(const float* dgates, const float* x, const float* hseq, 
                         int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
                         int64_t F, int64_t H, int dtype_mode, vts_stream_t stream);
 
+/* ---- The layer's three big products over bf16 plane operands (bench-sized shapes, dtype_mode 1) ----
+ * In bf16x3 mode every operand of a product is an fp32 value split into a bf16 head and a bf16 tail.  For the
+ * shapes vts_lstm_planes_supported() accepts (hidden 256, B a multiple of 128, T even) the sequences can be kept
+ * in that split form, as "planes": opaque buffers of 1 KiB tiles in matrix-core operand order, sized by
+ * vts_lstm_planes_bytes(B, T, F, is_hseq).  The recurrent kernels write the h sequence and the gate gradients as
+ * planes directly, the layer input is converted once (vts_lstm_planes_from_rows), and the input projection, data
+ * gradient and both weight gradients then run without converting or transposing anything.  An h-sequence plane
+ * buffer (is_hseq = 1) carries one more step slot, the zero initial state, so "h one step back" is an offset.
+ * Same arithmetic as the dtype_mode 1 entry points above (three bf16 MFMAs per fp32 product); results differ from
+ * them only in the order of the fp32 partial sums.  Workspace of every call: vts_lstm_planes_workspace_bytes().
+ * (autograd of nn.LSTM in the reference: vae-models/mixture-vae-DE.py:45,60,161 ; gpd-lstm-DE.py:18,27,102) */
+int vts_lstm_planes_supported(int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode);
+size_t vts_lstm_planes_bytes(int64_t B, int64_t T, int64_t F, int is_hseq);
+size_t vts_lstm_planes_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H);
+/* x [B,T,Cin] row-major -> planes (features zero-padded to a multiple of 64) */
+int vts_lstm_planes_from_rows(const float* x, void* x_planes, int64_t B, int64_t T, int64_t Cin, int64_t H,
+                              int dtype_mode, vts_stream_t stream);
+/* vts_lstm_inproj_fwd with the layer input as planes (x_is_hseq: it is the h-sequence buffer of the layer below) */
+int vts_lstm_inproj_fwd_planes(const void* x_planes, int x_is_hseq, const float* w_ih, const float* b_ih,
+                               const float* b_hh, float* gates, void* workspace, size_t workspace_bytes, int64_t B,
+                               int64_t T, int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream);
+/* vts_lstm_recurrent_fwd that also writes the h sequence as planes; hseq (fp32 [B,T,H]) may then be NULL */
+int vts_lstm_recurrent_fwd_planes(float* gates, float* cells, float* hseq, void* h_planes, float* h_last, float* c_last,
+                                  const float* w_hh, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
+                                  int64_t H, int dtype_mode, vts_stream_t stream);
+/* vts_lstm_recurrent_bwd that writes the gate pre-activation gradients as planes (vts_lstm_planes_bytes(B, T, 4H, 0))
+ * and leaves `gates` untouched */
+int vts_lstm_recurrent_bwd_planes(const float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
+                                  const float* dc_last, const float* w_hh, void* dg_planes, float* db_ih, float* db_hh,
+                                  int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
+                                  int64_t H, int dtype_mode, vts_stream_t stream);
+/* vts_lstm_dgrad from gate-gradient planes (Cin a multiple of 256) */
+int vts_lstm_dgrad_planes(const void* dg_planes, const float* w_ih, float* dx_t16, void* workspace,
+                          size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode,
+                          vts_stream_t stream);
+/* vts_lstm_wgrad_pair from planes: dw_ih (+)= dgates^T x, dw_hh (+)= dgates^T h(one step back), one launch */
+int vts_lstm_wgrad_planes(const void* dg_planes, const void* x_planes, int x_is_hseq, const void* h_planes, float* dw_ih,
+                          float* dw_hh, int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
+                          int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream);
+
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,
                        vts_stream_t stream);

@@ -1,0 +1,122 @@
+"""The LSTM layer's plane path (csrc/gemm_planes.h, csrc/lstm_planes.hip): sequences kept as bf16 head/tail planes
+between the recurrent kernels and the three big products.  Taken in bf16x3 mode for hidden 256, batches that are
+multiples of 128 and even step counts.  Oracle: torch's CPU nn.LSTM (what the reference calls:
+vae-models/mixture-vae-DE.py:45,60), tolerance L2-relative 1e-4 on outputs and every gradient, as everywhere."""
+import pytest
+import torch
+
+
+def l2_rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _bf16x3():
+    import vts
+    old = vts.get_mode()
+    vts.set_mode("bf16x3")
+    yield
+    vts.set_mode(old)
+
+
+def _planes_taken(B, T, C, H):
+    from vts import _lib
+    return bool(_lib.load().vts_lstm_planes_supported(B, T, C, H, 1))
+
+
+@pytest.mark.parametrize("B,T,C,H,layers", [
+    (128, 2, 8, 256, 1),      # one cluster, one weight-gradient k-step per window tile
+    (128, 6, 370, 256, 3),    # LD2011 channel count: input planes padded to 384, three column tiles of weight gradients
+    (256, 16, 1, 256, 2),     # a single input channel
+    (384, 4, 64, 256, 2),     # 96 token tiles: output tiles spread unevenly over the workgroups
+    (1024, 8, 256, 256, 3),   # 512 token tiles: more than one output tile per workgroup, 32 k-slices
+])
+@pytest.mark.parametrize("need_output", [True, False])
+def test_plane_path_matches_torch_lstm(B, T, C, H, layers, need_output):
+    import vts
+    assert _planes_taken(B, T, C, H)
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + T + C)
+    lstm = vts.LSTM(C, H, num_layers=layers).to(dev)
+    ref = torch.nn.LSTM(C, H, num_layers=layers, batch_first=True)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in lstm.state_dict().items()})
+    x = torch.randn(B, T, C, generator=g)
+    w_out = torch.randn(B, T, H, generator=g)
+    w_h = torch.randn(layers, B, H, generator=g)
+    w_c = torch.randn(layers, B, H, generator=g)
+
+    out_r, (hn_r, cn_r) = ref(x)
+    loss_r = (hn_r * w_h).sum() + (cn_r * w_c).sum()
+    if need_output:
+        loss_r = loss_r + (out_r * w_out).sum()
+    loss_r.backward()
+
+    out, (hn, cn) = lstm(x.to(dev), need_output=need_output)
+    loss = (hn * w_h.to(dev)).sum() + (cn * w_c.to(dev)).sum()
+    if need_output:
+        loss = loss + (out * w_out.to(dev)).sum()
+        assert l2_rel(out, out_r) < TOL
+    else:
+        assert out.numel() == 0
+    loss.backward()
+    assert l2_rel(hn, hn_r) < TOL
+    assert l2_rel(cn, cn_r) < TOL
+    for k, p in lstm.named_parameters():
+        assert l2_rel(p.grad, getattr(ref, k).grad) < TOL, k
+
+
+def test_plane_path_input_gradient():
+    """Input width 256: the first layer's data gradient runs on the plane path too."""
+    import vts
+    B, T, C, H = 128, 4, 256, 256
+    assert _planes_taken(B, T, C, H)
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    lstm = vts.LSTM(C, H, num_layers=2).to(dev)
+    ref = torch.nn.LSTM(C, H, num_layers=2, batch_first=True)
+    ref.load_state_dict({k: v.cpu() for k, v in lstm.state_dict().items()})
+    x = torch.randn(B, T, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    xd = x.to(dev).requires_grad_(True)
+    ref(xr)[1][0][-1].pow(2).sum().backward()
+    lstm(xd)[1][0][-1].pow(2).sum().backward()
+    assert l2_rel(xd.grad, xr.grad) < TOL
+    for k, p in lstm.named_parameters():
+        assert l2_rel(p.grad, getattr(ref, k).grad) < TOL, k
+
+
+def test_second_backward_on_the_plane_path():
+    """The plane path leaves the saved gate activations alone, so a retained graph can be differentiated twice."""
+    import vts
+    dev = _dev()
+    lstm = vts.LSTM(8, 256).to(dev)
+    x = torch.randn(128, 4, 8, device=dev)
+    _, (hn, _) = lstm(x, need_output=False)
+    loss = hn.pow(2).sum()
+    loss.backward(retain_graph=True)
+    first = [p.grad.clone() for p in lstm.parameters()]
+    for p in lstm.parameters():
+        p.grad = None
+    loss.backward()
+    for a, p in zip(first, lstm.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+def test_second_backward_off_the_plane_path_raises():
+    import vts
+    dev = _dev()
+    lstm = vts.LSTM(8, 64).to(dev)
+    x = torch.randn(16, 4, 8, device=dev)
+    _, (hn, _) = lstm(x)
+    loss = hn.pow(2).sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss.backward()

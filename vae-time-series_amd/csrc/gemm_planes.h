@@ -64,8 +64,22 @@ __device__ __forceinline__ void wait_frag(u32x4& x, u32x4& y) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y));
 }
 
-// Pol::a_tile(li, s) / b_tile(li, s): global address of tile li (0..31) of the operand's half stage at k-step s
-// (0 .. nsteps-1).  Wave-uniform.  Order of the 32 tiles:
+// Sequence operand as planes: tokens (window b, step t) in tiles of 16 windows (batch tile bt = b / 16) at one
+// step, `ncb` column blocks of 32 features, `ts` step slots per batch tile of which step t sits in slot t0 + t
+// (the h sequence keeps a zero tile in slot 0 - the initial state - so that "the step before" is a plain offset).
+struct SeqPlanes {
+  char* base;
+  int ncb, ts, t0;
+  __host__ __device__ long tile(long bt, int t, int cb, int p) const {
+    return ((((bt * ts) + t0 + t) * ncb + cb) * 2 + p) * (long)TILE_B;
+  }
+  __host__ __device__ size_t bytes(long nbt) const { return (size_t)nbt * ts * ncb * 2 * TILE_B; }
+};
+
+// Policy interface.  pol.advance() is called once per k-step, in order, before that k-step's loads are issued
+// (wave-uniform bookkeeping); pol.a_tile(li) / pol.b_tile(li) then give the global address of tile li (0..31) of
+// the operand's half stage for that k-step; pol.flush(acc) is called after the products of every nk-th k-step with
+// the finished accumulators (which are cleared afterwards).  Order of the 32 tiles:
 //   TRANS = false: li = 2 * i + p      row tile i (0..15) of the workgroup's 256 rows, plane p (0 hi, 1 lo);
 //   TRANS = true : li = (tt * 8 + cb) * 2 + p   tile tt (0, 1) of the k-step's two row tiles, column block cb
 //                  (32 columns each, 0..7) of the workgroup's 256 output rows (A) or columns (B), plane p.
@@ -77,7 +91,8 @@ __device__ __forceinline__ void wait_frag(u32x4& x, u32x4& y) {
 // counted (each wave issues eight per k-step, vmcnt(8) retires everything but the newest eight) and the barriers
 // are bare s_barrier instructions.  A slot is read only after a barrier that follows the wait that retired it.
 template <class Pol, bool TRANS, int DBG = 0>   // DBG (timing experiments only): 1 = no global loads, 2 = no products
-__device__ __forceinline__ void mainloop(const Pol& pol, int nsteps, char* lds, f32x4 (&acc)[4][8]) {
+__device__ __forceinline__ void mainloop(Pol& pol, int nsteps, int nk, char* lds) {
+  f32x4 acc[4][8];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -88,10 +103,10 @@ __device__ __forceinline__ void mainloop(const Pol& pol, int nsteps, char* lds, 
   if (nsteps <= 0) return;
 
   // piece q (0..7) of a wave's loads for k-step s: q < 4 -> A tile 4 * wave + q; q >= 4 -> B tile 4 * wave + q - 4
-  auto issue_piece = [&](int s, int slot_a, int slot_b, int q) {
+  auto issue_piece = [&](int slot_a, int slot_b, int q) {
     const int li = 4 * wave + (q & 3);
-    if (q < 4) glds16(pol.a_tile(li, s) + lane * 16, lds + slot_a * HALF_B + li * TILE_B);
-    else       glds16(pol.b_tile(li, s) + lane * 16, lds + slot_b * HALF_B + li * TILE_B);
+    if (q < 4) glds16(pol.a_tile(li) + lane * 16, lds + slot_a * HALF_B + li * TILE_B);
+    else       glds16(pol.b_tile(li) + lane * 16, lds + slot_b * HALF_B + li * TILE_B);
   };
   auto next2 = [](int sl) { return sl >= 3 ? sl - 3 : sl + 2; };   // (sl + 2) % 5
 
@@ -119,11 +134,13 @@ __device__ __forceinline__ void mainloop(const Pol& pol, int nsteps, char* lds, 
   };
 
   if (DBG != 1) {
+    pol.advance();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) issue_piece(0, 0, 1, q);
+    for (int q = 0; q < 8; ++q) issue_piece(0, 1, q);
     if (nsteps > 1) {
+      pol.advance();
 #pragma unroll
-      for (int q = 0; q < 8; ++q) issue_piece(1, 2, 3, q);
+      for (int q = 0; q < 8; ++q) issue_piece(2, 3, q);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -132,6 +149,7 @@ __device__ __forceinline__ void mainloop(const Pol& pol, int nsteps, char* lds, 
   __builtin_amdgcn_s_barrier();
 
   int sa = 0;   // slot of A_s; B_s is in sa + 1 (mod 5)
+  int kleft = nk;
   for (int s = 0; s < nsteps; ++s) {
     const int sb = sa == 4 ? 0 : sa + 1;
     const int sa2 = next2(next2(sa)), sb2 = sa;        // slots of A_{s+2}, B_{s+2}
@@ -153,11 +171,12 @@ __device__ __forceinline__ void mainloop(const Pol& pol, int nsteps, char* lds, 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // every wave holds its A fragments: A_s's slot is free
+    if (more) pol.advance();
     // B fragments one column tile ahead of their MFMAs; the scheduling fences keep the compiler from hoisting
     // all sixteen fragment reads to the top (128 registers) and spilling the accumulators.
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      if (more) issue_piece(s + 2, sa2, sb2, nt);
+      if (more) issue_piece(sa2, sb2, nt);
       if (DBG != 2) {
         if (TRANS) wait_frag(bh, bl);
         u32x4 nh = bh, nl = bl;
@@ -183,6 +202,14 @@ __device__ __forceinline__ void mainloop(const Pol& pol, int nsteps, char* lds, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     sa = next2(sa);
+    if (--kleft == 0) {
+      kleft = nk;
+      pol.flush(acc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 }
 

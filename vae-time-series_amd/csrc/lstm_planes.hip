@@ -1,0 +1,370 @@
+// The LSTM layer's three big products over bf16 plane operands (gemm_planes.h): input projection, data gradient
+// and the paired weight gradients, plus the conversions that put an fp32 input sequence and the weights into
+// plane form.  The recurrent kernels write the h sequence and the gate gradients as planes themselves, so none of
+// these products converts or transposes anything: tiles go from HBM to LDS by DMA and from LDS to the matrix cores.
+//
+// Column order of the gate gradients.  The backward recurrence keeps dA in LDS with the four gates of a hidden
+// unit side by side (k' = 4 * j + gate for gate-major column n = gate * H + j) and writes its planes in that
+// order.  The data-gradient product contracts over k', so its weight operand is packed in the same order; the
+// weight-gradient product has k' as its output row and un-permutes when it reduces the split-K slabs.
+#include "gemm_planes.h"
+
+namespace {
+
+using gp::SeqPlanes;
+using gp::TILE_B;
+
+__device__ __forceinline__ int gate_major(int kp, int H) { return (kp & 3) * H + (kp >> 2); }
+
+// ---- conversions ------------------------------------------------------------------------------------------
+// One thread per 16-byte slot pair (hi and lo): row r of the tile, k-group g (8 consecutive features).
+__global__ __launch_bounds__(256) void rows_to_planes_kernel(const float* __restrict__ x, SeqPlanes out, int B, int T,
+                                                             int C, long nslots) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (long)gridDim.x * blockDim.x) {
+    const int l = i & 63;
+    long rest = i >> 6;
+    const int cb = rest % out.ncb; rest /= out.ncb;
+    const int t = rest % T;
+    const long bt = rest / T;
+    const int g = l & 3, r = l >> 2;          // 4 consecutive threads read 128 contiguous bytes of one row
+    const long b = bt * 16 + r;
+    const int c0 = cb * 32 + g * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (b < B && c0 + e < C) ? x[(b * T + t) * C + c0 + e] : 0.f;
+    gp::u32x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h_, l_;
+      split2(v[2 * q], v[2 * q + 1], h_, l_);
+      hi[q] = h_; lo[q] = l_;
+    }
+    char* tile = out.base + out.tile(bt, t, cb, 0);
+    *reinterpret_cast<gp::u32x4*>(tile + gp::slot(g, r) * 16) = hi;
+    *reinterpret_cast<gp::u32x4*>(tile + TILE_B + gp::slot(g, r) * 16) = lo;
+  }
+}
+
+// Weight operand planes [row tile][cb][p].  kind 0: rows = gate column n (gate-major), k = input feature c
+// (input projection: W[n][c]); kind 1: rows = input feature c, k = k' (data gradient: W[gate_major(k')][c]).
+__global__ __launch_bounds__(256) void weights_to_planes_kernel(const float* __restrict__ W, int N4H, int C, int H,
+                                                                int kind, char* __restrict__ out, int nrt, int ncb) {
+  const long nslots = (long)nrt * ncb * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (long)gridDim.x * blockDim.x) {
+    const int l = i & 63;
+    long rest = i >> 6;
+    const int cb = rest % ncb;
+    const int rt = rest / ncb;
+    const int g = l >> 4, r = l & 15;
+    const int row = rt * 16 + r, k0 = cb * 32 + g * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + e;
+      if (kind == 0) v[e] = (row < N4H && k < C) ? W[(long)row * C + k] : 0.f;
+      else           v[e] = (row < C && k < N4H) ? W[(long)gate_major(k, H) * C + row] : 0.f;
+    }
+    gp::u32x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h_, l_;
+      split2(v[2 * q], v[2 * q + 1], h_, l_);
+      hi[q] = h_; lo[q] = l_;
+    }
+    char* tile = out + ((long)(rt * ncb + cb) * 2) * TILE_B;
+    *reinterpret_cast<gp::u32x4*>(tile + gp::slot(g, r) * 16) = hi;
+    *reinterpret_cast<gp::u32x4*>(tile + TILE_B + gp::slot(g, r) * 16) = lo;
+  }
+}
+
+__global__ void zero_slot0_kernel(SeqPlanes p, long nbt) {   // the zero "step before the first" of an h sequence
+  const long n16 = (long)p.ncb * 2 * (TILE_B / 16);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nbt * n16; i += (long)gridDim.x * blockDim.x) {
+    const long bt = i / n16, o = i % n16;
+    *reinterpret_cast<gp::u32x4*>(p.base + (bt * p.ts) * p.ncb * 2 * TILE_B + o * 16) = gp::u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
+// ---- rows x weights: input projection and data gradient ------------------------------------------------------
+// out[tile16 of [tokens, N]] = A[tokens, K] . Wt[N, K]^T (+ bias0 + bias1).  A workgroup owns a run of output
+// tiles (256 tokens x 256 columns, the column tiles of a token block one after the other, so the block's A tiles
+// are re-read from the L2) and streams their k-steps as one sequence through the ring: the loads of the next
+// tile's first k-steps are in flight while a tile's accumulators are written out.
+struct RowPol {
+  SeqPlanes A;
+  const char* W; int w_ncb;
+  int T, nk, ntn, N;
+  float* out; const float* bias0; const float* bias1;
+  int wave, lane;
+  int is_tile, is_ks, fl_tile;
+  const char *a0, *a1, *b0, *b1;
+  __device__ __forceinline__ void advance() {
+    if (++is_ks == nk) {
+      is_ks = 0;
+      ++is_tile;
+      const int tb = is_tile / ntn, tn = is_tile - tb * ntn;
+      const int idx = tb * 16 + 2 * wave;             // first of this wave's two token tiles (T is even: same window tile)
+      const int bt = idx / T, t = idx - bt * T;
+      a0 = A.base + A.tile(bt, t, 0, 0);
+      a1 = a0 + A.ncb * 2 * TILE_B;
+      b0 = W + (long)(tn * 16 + 2 * wave) * w_ncb * 2 * TILE_B;
+      b1 = b0 + w_ncb * 2 * TILE_B;
+    }
+  }
+  // li = 4 * wave + q: row tile 2 * wave + (q >> 1), plane q & 1
+  __device__ __forceinline__ const char* a_tile(int li) const { return ((li & 2) ? a1 : a0) + (is_ks * 2 + (li & 1)) * TILE_B; }
+  __device__ __forceinline__ const char* b_tile(int li) const { return ((li & 2) ? b1 : b0) + (is_ks * 2 + (li & 1)) * TILE_B; }
+  __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) {
+    const int tile = fl_tile++;
+    const int tb = tile / ntn, tn = tile - tb * ntn;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const int ct = tn * 16 + wn * 8 + nt;
+      float bias = 0.f;
+      if (bias0 != nullptr) bias = bias0[ct * 16 + r] + bias1[ct * 16 + r];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const long tt = (long)tb * 16 + wm * 4 + mt;
+        f32x4 v = acc[mt][nt];
+        v += bias;
+        *reinterpret_cast<f32x4*>(out + (tt * (N / 16) + ct) * 256 + lane * 4) = v;
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(512) void rowgemm_planes_kernel(SeqPlanes A, const char* W, int w_ncb, int T, int nk,
+                                                             int ntn, int N, float* out, const float* bias0,
+                                                             const float* bias1, int ntiles_all) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  // contiguous runs of tiles per workgroup, token-block aligned where possible
+  const long lo = (long)blockIdx.x * ntiles_all / gridDim.x, hi = (long)(blockIdx.x + 1) * ntiles_all / gridDim.x;
+  const int n = (int)(hi - lo);
+  if (n <= 0) return;
+  RowPol pol;
+  pol.A = A; pol.W = W; pol.w_ncb = w_ncb; pol.T = T; pol.nk = nk; pol.ntn = ntn; pol.N = N;
+  pol.out = out; pol.bias0 = bias0; pol.bias1 = bias1;
+  pol.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  pol.lane = threadIdx.x & 63;
+  pol.is_tile = (int)lo - 1; pol.is_ks = nk - 1; pol.fl_tile = (int)lo;
+  gp::mainloop<RowPol, false>(pol, n * nk, nk, lds);
+}
+
+// ---- weight gradients ---------------------------------------------------------------------------------------
+// slab[z][m'][n] = sum over the k-steps of slice z of dG[token][m'] * B[token][n], B = [layer input | h one step
+// back | zero padding].  Both operands are read with the transposed fragment read; a k-step is two token tiles.
+struct WgradPol {
+  SeqPlanes dG, X, Hs;          // Hs.t0 = 0: slot t holds h_{t-1}
+  int T;
+  int ncb_x, ncb_h;
+  const char* zero;
+  float* slab; int Ntot;
+  int tm, tn, wave, lane;
+  long bt; int t;               // token tiles (bt, t), (bt, t + 1) of the k-step being issued
+  const char *a, *b;
+  __device__ __forceinline__ void advance() {
+    t += 2;
+    if (t >= T) { t = 0; ++bt; }
+    const int tt = wave >> 2, cbl = 2 * (wave & 3);        // this wave's tiles: token tile tt, column blocks cbl, cbl + 1
+    a = dG.base + dG.tile(bt, t + tt, tm * 8 + cbl, 0);
+    const int cbg = tn * 8 + cbl;
+    if (cbg < ncb_x) b = X.base + X.tile(bt, t + tt, cbg, 0);
+    else if (cbg - ncb_x < ncb_h) b = Hs.base + Hs.tile(bt, t + tt, cbg - ncb_x, 0);
+    else b = nullptr;
+  }
+  // li = 4 * wave + q: column block cbl + (q >> 1), plane q & 1: four consecutive KiB
+  __device__ __forceinline__ const char* a_tile(int li) const { return a + (li & 3) * TILE_B; }
+  __device__ __forceinline__ const char* b_tile(int li) const { return b != nullptr ? b + (li & 3) * TILE_B : zero; }
+  __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) {
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = tm * 256 + (wm * 4 + mt) * 16 + 4 * g + reg;
+          const int col = tn * 256 + (wn * 8 + nt) * 16 + r;
+          slab[(long)row * Ntot + col] = acc[mt][nt][reg];
+        }
+  }
+};
+
+__global__ __launch_bounds__(512) void wgrad_planes_kernel(SeqPlanes dG, SeqPlanes X, SeqPlanes Hs, int T, int ncb_x,
+                                                           int ncb_h, const char* zero, float* slabs, int M, int Ntot,
+                                                           int nsteps_all, int ksplit) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tiles_m = M / gp::TM, tiles_n = Ntot / gp::TN, per = tiles_m * tiles_n;
+  // slices of one XCD's share sit on that XCD together with all their tiles: an operand tile is fetched from HBM
+  // once and served to the other workgroups of its slice by the L2
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int z = (j / per) * 8 + xcd, tile = j % per;
+  if (z >= ksplit) return;
+  const int chunk = (nsteps_all + ksplit - 1) / ksplit;
+  const int s0 = z * chunk;
+  const int n = min(chunk, nsteps_all - s0);
+  WgradPol pol;
+  pol.dG = dG; pol.X = X; pol.Hs = Hs; pol.T = T; pol.ncb_x = ncb_x; pol.ncb_h = ncb_h; pol.zero = zero;
+  pol.slab = slabs + (long)z * M * Ntot; pol.Ntot = Ntot;
+  pol.tm = tile / tiles_n; pol.tn = tile % tiles_n;
+  pol.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  pol.lane = threadIdx.x & 63;
+  const long idx = 2L * s0 - 2;                // advance() steps to 2 * s0 first
+  pol.bt = idx >= 0 ? idx / T : -1;
+  pol.t = idx >= 0 ? (int)(idx - pol.bt * T) : T - 2;
+  if (n <= 0) {                                // an empty slice still owns a slab: zero it
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pol.flush(acc);
+    return;
+  }
+  gp::mainloop<WgradPol, true>(pol, n, n, lds);
+}
+
+// dw_ih[gate_major(m')][c] (+)= sum_z slab[z][m'][c], c < F;  dw_hh[gate_major(m')][j] (+)= sum_z slab[z][m'][Fp + j]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int M, int Ntot,
+                                                           int F, int Fp, int H, float* __restrict__ dw_ih,
+                                                           float* __restrict__ dw_hh, int accumulate) {
+  const long total = (long)M * (Fp + H);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = i / (Fp + H), n = i % (Fp + H);
+    if (n >= F && n < Fp) continue;
+    const float* p = slabs + (long)m * Ntot + n;
+    float s0 = 0.f, s1 = 0.f;
+    int z = 0;
+    for (; z + 1 < ksplit; z += 2) {
+      s0 += p[(long)z * M * Ntot];
+      s1 += p[(long)(z + 1) * M * Ntot];
+    }
+    if (z < ksplit) s0 += p[(long)z * M * Ntot];
+    const float s = s0 + s1;
+    const int row = gate_major(m, H);
+    float* dst = n < F ? dw_ih + (long)row * F + n : dw_hh + (long)row * H + (n - Fp);
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+unsigned long long g_lds_row = 0, g_lds_wgrad = 0;
+
+int grid_cus() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    cus = 256;
+  return cus > 0 ? cus : 256;
+}
+
+}  // namespace
+
+// ---- host side ------------------------------------------------------------------------------------------------
+// Shapes the plane path is built for: hidden 256 (gate columns fill whole 256-row tiles), whole clusters of 128
+// windows, an even number of steps (a weight-gradient k-step is two token tiles of one window tile).
+bool vts_planes_usable(long B, long T, long H) { return H == 256 && B > 0 && (B % 128) == 0 && T >= 2 && (T % 2) == 0; }
+int vts_planes_fpad(long F) { return (int)((F + 63) / 64 * 64); }
+size_t vts_planes_seq_bytes(long B, long T, long F, int with_zero_slot) {
+  const long nbt = (B + 15) / 16;
+  return (size_t)nbt * (T + (with_zero_slot ? 1 : 0)) * (vts_planes_fpad(F) / 32) * 2 * TILE_B;
+}
+size_t vts_planes_weight_bytes(long rows, long K) {
+  return (size_t)((rows + 15) / 16) * (vts_planes_fpad(K) / 32) * 2 * TILE_B;
+}
+static SeqPlanes seq_planes(void* base, long T, long F, int with_zero_slot) {
+  return SeqPlanes{reinterpret_cast<char*>(base), vts_planes_fpad(F) / 32, (int)T + (with_zero_slot ? 1 : 0),
+                   with_zero_slot ? 1 : 0};
+}
+
+int vts_planes_from_rows(const float* x, void* planes, long B, long T, long C, hipStream_t st) {
+  SeqPlanes P = seq_planes(planes, T, C, 0);
+  const long nbt = (B + 15) / 16, nslots = nbt * T * P.ncb * 64;
+  hipLaunchKernelGGL(rows_to_planes_kernel, dim3((unsigned)((nslots + 255) / 256 > 65536 * 4 ? 65536 * 4 : (nslots + 255) / 256)),
+                     dim3(256), 0, st, x, P, (int)B, (int)T, (int)C, nslots);
+  VTS_CHECK_LAUNCH("rows_to_planes");
+  return VTS_OK;
+}
+
+int vts_planes_zero_slot0(void* planes, long B, long T, long F, hipStream_t st) {
+  SeqPlanes P = seq_planes(planes, T, F, 1);
+  const long nbt = (B + 15) / 16;
+  hipLaunchKernelGGL(zero_slot0_kernel, dim3((unsigned)((nbt * P.ncb * 128 + 255) / 256)), dim3(256), 0, st, P, nbt);
+  VTS_CHECK_LAUNCH("zero_slot0");
+  return VTS_OK;
+}
+
+// gates[tile16 of [B*T, 4H]] = S . W_ih^T + b_ih + b_hh; S planes with (a_zero_slot ? the h-sequence layout : T slots)
+int vts_planes_inproj(const void* s_planes, int a_zero_slot, const float* w_ih, const float* b_ih, const float* b_hh,
+                      float* gates, void* wplanes, long B, long T, long Cin, long H, hipStream_t st) {
+  const int N = (int)(4 * H), Fp = vts_planes_fpad(Cin), ncb = Fp / 32;
+  hipLaunchKernelGGL(weights_to_planes_kernel, dim3((N / 16) * ncb / 4), dim3(256), 0, st, w_ih, N, (int)Cin, (int)H, 0,
+                     reinterpret_cast<char*>(wplanes), N / 16, ncb);
+  VTS_CHECK_LAUNCH("weights_to_planes");
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(rowgemm_planes_kernel), gp::LDS_B, &g_lds_row, "rowgemm_planes")) return rc;
+  SeqPlanes A = seq_planes(const_cast<void*>(s_planes), T, Cin, a_zero_slot);
+  const int ntb = (int)(B / 16 * T / 16), ntn = N / 256;
+  const int grid = min(grid_cus(), ntb);
+  hipLaunchKernelGGL(rowgemm_planes_kernel, dim3(grid), dim3(512), gp::LDS_B, st, A, reinterpret_cast<const char*>(wplanes),
+                     ncb, (int)T, ncb, ntn, N, gates, b_ih, b_hh, ntb * ntn);
+  VTS_CHECK_LAUNCH("rowgemm_planes(inproj)");
+  return VTS_OK;
+}
+
+// dx[tile16 of [B*T, Cin]] = dG . W_ih  (dG planes in k' order, Cin a multiple of 256)
+int vts_planes_dgrad(const void* dg_planes, const float* w_ih, float* dx_t16, void* wplanes, long B, long T, long Cin,
+                     long H, hipStream_t st) {
+  const int N4H = (int)(4 * H), ncb = N4H / 32;
+  hipLaunchKernelGGL(weights_to_planes_kernel, dim3((int)(Cin / 16) * ncb / 4), dim3(256), 0, st, w_ih, N4H, (int)Cin, (int)H, 1,
+                     reinterpret_cast<char*>(wplanes), (int)(Cin / 16), ncb);
+  VTS_CHECK_LAUNCH("weights_to_planes");
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(rowgemm_planes_kernel), gp::LDS_B, &g_lds_row, "rowgemm_planes")) return rc;
+  SeqPlanes A = seq_planes(const_cast<void*>(dg_planes), T, N4H, 0);
+  const int ntb = (int)(B / 16 * T / 16), ntn = (int)(Cin / 256);
+  const int grid = min(grid_cus(), ntb);
+  hipLaunchKernelGGL(rowgemm_planes_kernel, dim3(grid), dim3(512), gp::LDS_B, st, A, reinterpret_cast<const char*>(wplanes),
+                     ncb, (int)T, ncb, ntn, (int)Cin, dx_t16, nullptr, nullptr, ntb * ntn);
+  VTS_CHECK_LAUNCH("rowgemm_planes(dgrad)");
+  return VTS_OK;
+}
+
+// split-K plan of the paired weight gradients: column tiles over [Fp | H] padded to 256, slices in multiples of 8
+static void wgrad_plan(long B, long T, long F, long H, int* Ntot, int* ksplit, int* nsteps) {
+  const int Fp = vts_planes_fpad(F);
+  *Ntot = (int)((Fp + H + 255) / 256 * 256);
+  const int per = (int)(4 * H / 256) * (*Ntot / 256);
+  *nsteps = (int)(B / 16 * T / 2);
+  int ks = 8 * ((grid_cus() / 8) / per);
+  if (ks < 8) ks = 8;
+  while (ks > 8 && *nsteps / ks < 8) ks -= 8;
+  *ksplit = ks;
+}
+size_t vts_planes_wgrad_slab_bytes(long B, long T, long F, long H) {
+  int Ntot, ksplit, nsteps;
+  wgrad_plan(B, T, F, H, &Ntot, &ksplit, &nsteps);
+  return (size_t)ksplit * 4 * H * Ntot * sizeof(float);
+}
+
+// dw_ih[4H, F] (+)= dG^T . S,  dw_hh[4H, H] (+)= dG^T . h(one step back): one launch + the slab reduction.
+// x_zero_slot: S is an h sequence (slot 0 = zeros) rather than a converted input.
+int vts_planes_wgrad(const void* dg_planes, const void* s_planes, int x_zero_slot, const void* h_planes, float* dw_ih,
+                     float* dw_hh, int accumulate, float* slabs, long B, long T, long F, long H, hipStream_t st) {
+  int Ntot, ksplit, nsteps;
+  wgrad_plan(B, T, F, H, &Ntot, &ksplit, &nsteps);
+  const int M = (int)(4 * H), Fp = vts_planes_fpad(F);
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(wgrad_planes_kernel), gp::LDS_B, &g_lds_wgrad, "wgrad_planes")) return rc;
+  SeqPlanes dG = seq_planes(const_cast<void*>(dg_planes), T, M, 0);
+  SeqPlanes X = seq_planes(const_cast<void*>(s_planes), T, F, x_zero_slot);
+  SeqPlanes Hs = seq_planes(const_cast<void*>(h_planes), T, H, 1);
+  Hs.t0 = 0;                                        // slot t = h_{t-1}; slot 0 = the zero initial state
+  const char* zero = Hs.base;                       // (bt 0, slot 0, cb 0): 2 KiB of zeros
+  const int per = (M / 256) * (Ntot / 256);
+  hipLaunchKernelGGL(wgrad_planes_kernel, dim3(8 * (ksplit / 8) * per), dim3(512), gp::LDS_B, st, dG, X, Hs, (int)T,
+                     Fp / 32, (int)(H / 32), zero, slabs, M, Ntot, nsteps, ksplit);
+  VTS_CHECK_LAUNCH("wgrad_planes");
+  const long total = (long)M * (Fp + H);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, ksplit, M, Ntot,
+                     (int)F, Fp, (int)H, dw_ih, dw_hh, accumulate);
+  VTS_CHECK_LAUNCH("wgrad_reduce");
+  return VTS_OK;
+}

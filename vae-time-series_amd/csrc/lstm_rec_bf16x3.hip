@@ -11,6 +11,7 @@
 // planes.  With the matrix-core time out of the way the kernels run at the rate the XCD's L2
 // delivers the W_hh image to 32 CUs at once (~70 GB/s per CU), so part of the image stays in LDS.
 #include "lstm_rec_common.h"
+#include "gemm_planes.h"
 #include <type_traits>
 
 namespace {
@@ -96,10 +97,13 @@ __global__ void pack_whh3_kernel(const float* __restrict__ W, u32x4* __restrict_
 // Arguments as lstm_rec_fwd_kernel.  LDS: h as bf16 planes [buffer 2][hi, lo][16][H], the 16-byte
 // chunk index XOR-ed with the row (conflict-free fragment reads without padding), then the
 // second lo half-unit of every odd k-step (a quarter of the lo plane, 1/8 of the image).
-template <int H>
+// PL: the h sequence also goes out as bf16 planes (gemm_planes.h; hp: T + 1 step slots per window tile, slot 0 =
+// the zero initial state): the A fragments a step's product reads from LDS are exactly the tiles of h_{t-1}, so
+// wave w stores the fragments of k-steps w and w + 4 as it uses them; hseq may then be null.
+template <int H, bool PL>
 __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
     float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
-    float* __restrict__ clast, const u32x4* __restrict__ Wp, int B, int T) {
+    float* __restrict__ clast, const u32x4* __restrict__ Wp, int B, int T, gp::SeqPlanes hp) {
   using C = RecCfg<H>;
   using R = Rec3Cfg<H>;
   constexpr int NT = R::NT;
@@ -146,6 +150,13 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
   };
 
   float* hseq_wg = hseq + (long)b0 * T * H;   // uniform base; lane offsets stay below 16*T*H
+  const unsigned pl_off = gp::slot(g, r) * 16;
+  if (PL) {
+#pragma unroll
+    for (int i = 0; i < 2 * KS / C::NW; ++i)   // zero slot: column blocks wave, wave + NW, ..., both planes
+      __builtin_nontemporal_store(u32x4{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4*>(
+          hp.base + hp.tile(bt, -1, wave + C::NW * (i >> 1), i & 1) + lane * 16));
+  }
   f32x4 gnext[NT];
   load_g(gnext, 0);
   u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
@@ -195,9 +206,14 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
       };
       // One k-step.  RES: its last half-unit comes from LDS instead of the stream.  Younger loads
       // at each wait: the two (RES) or three half-units issued after the one being waited for.
+      char* hp_t = PL ? hp.base + hp.tile(bt, t - 1, 0, 0) : nullptr;     // tiles of h_{t-1}
       auto kstep = [&](int ks, auto res_tag) {
         constexpr bool RES = decltype(res_tag)::value;
         constexpr int NY = (RES ? 2 : 3) * UT;
+        if (PL && (ks & (C::NW - 1)) == wave) {
+          __builtin_nontemporal_store(ah, reinterpret_cast<u32x4*>(hp_t + ks * (2 * gp::TILE_B) + pl_off));
+          __builtin_nontemporal_store(al, reinterpret_cast<u32x4*>(hp_t + ks * (2 * gp::TILE_B) + gp::TILE_B + pl_off));
+        }
         if constexpr (RES) load_w_lds(w3, ks >> 1);
         else w_issue<UT>(w3, hu_ptr(ks, 3), voff);
         const int kn = (ks + 1) & (KS - 1);
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
         const int off = row * (H * 2) + ((((col >> 3) ^ (row & R::SWZ_F)) << 4) | ((col & 7) << 1));
         *reinterpret_cast<unsigned*>(hnxt + (odd ? PLANE : 0) + off) = odd ? lo : hi;
         if (b0 + row < B) {
-          hseq_wg[(unsigned)((row * T + t) * H + jt * 16 + r)] = hv;
+          if (hseq != nullptr) hseq_wg[(unsigned)((row * T + t) * H + jt * 16 + r)] = hv;
           if (t == T - 1) {
             if (hlast != nullptr) hlast[(long)(b0 + row) * H + jt * 16 + r] = hv;
             if (clast != nullptr) clast[(long)(b0 + row) * H + jt * 16 + r] = c[jl][reg];
@@ -269,6 +285,15 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
   w_wait<0, UT>(w0);
   w_wait<0, UT>(w1);
   w_wait<0, UT>(w2);
+  if (PL) {   // h_{T-1}: no product reads it, copy its tiles out of LDS (the barrier that ended the last step covers it)
+    const unsigned char* hl = smem3 + (T & 1) * (2 * PLANE);
+    char* hp_t = hp.base + hp.tile(bt, T - 1, 0, 0);
+    for (int ks = wave; ks < KS; ks += C::NW)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(hl + p * PLANE + a_off(ks)),
+                                    reinterpret_cast<u32x4*>(hp_t + (ks * 2 + p) * gp::TILE_B + pl_off));
+  }
 }
 
 // ---- backward -----------------------------------------------------------------------------------
@@ -277,11 +302,14 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
 // dA split into bf16 planes in LDS ([buffer 2][hi, lo][16][4H], chunk index XOR-ed with the row,
 // k slot = 4*hidden + gate) and the image streamed one k-step (JPW hi + JPW lo fragments) per
 // ring buffer, three k-steps in flight.
-template <int H>
+// PL: the gate gradients go out as bf16 planes (dgp: T step slots per window tile, columns in the k' = 4 * hidden +
+// gate order of the LDS image) instead of fp32 tile16 blocks into G, which is then left as it was: the A fragments
+// the product of step t + 1 reads from LDS are the tiles of dA_{t+1}, and wave w stores those of k-steps = w (mod 4).
+template <int H, bool PL>
 __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
     float* __restrict__ G, const float* __restrict__ cseq, const float* __restrict__ dhseq,
     const float* __restrict__ dhlast, const float* __restrict__ dclast, float* __restrict__ dbpart,
-    const u32x4* __restrict__ Wp, int B, int T) {
+    const u32x4* __restrict__ Wp, int B, int T, gp::SeqPlanes dgp) {
   using C = RecCfg<H>;
   using R = Rec3Cfg<H>;
   constexpr int JPW = C::JPW;
@@ -311,6 +339,7 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
   }
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(Wp) + (size_t)wave * (KS * UT * 1024);
   const unsigned voff = lane * 16;
+  const unsigned pl_off = gp::slot(g, r) * 16;
   auto ks_ptr = [&](int ks) { return wbase + (size_t)(ks * UT) * 1024; };
 
   auto load_step = [&](f32x4 (&gv)[JPW * 4], f32x4 (&dv)[JPW], int t) {
@@ -390,10 +419,12 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
       dbs[jl][1] += (daf[0] + daf[1]) + (daf[2] + daf[3]);
       dbs[jl][2] += (dag[0] + dag[1]) + (dag[2] + dag[3]);
       dbs[jl][3] += (dao[0] + dao[1]) + (dao[2] + dao[3]);
-      st_stream(Gt + (long)(0 * C::JT + jt) * 256, dai);
-      st_stream(Gt + (long)(1 * C::JT + jt) * 256, daf);
-      st_stream(Gt + (long)(2 * C::JT + jt) * 256, dag);
-      st_stream(Gt + (long)(3 * C::JT + jt) * 256, dao);
+      if (!PL) {
+        st_stream(Gt + (long)(0 * C::JT + jt) * 256, dai);
+        st_stream(Gt + (long)(1 * C::JT + jt) * 256, daf);
+        st_stream(Gt + (long)(2 * C::JT + jt) * 256, dag);
+        st_stream(Gt + (long)(3 * C::JT + jt) * 256, dao);
+      }
       // one hidden tile at a time: interleaving the four tiles' arithmetic quadruples the
       // temporaries live at once, and this kernel has no registers to spare
       __builtin_amdgcn_sched_barrier(0);
@@ -421,9 +452,14 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
     u32x4 ah = lds_a(0, 0), al = lds_a(1, 0);
     // one k-step: fragments w[0..JPW) = hi, w[JPW..2*JPW) = lo of this wave's JPW output tiles; `allowed` = how
     // many younger vector-memory loads may still be outstanding when this buffer's loads have landed
+    char* dg_t = PL ? dgp.base + dgp.tile(bt, t + 1, 0, 0) : nullptr;     // tiles of dA_{t+1}
     auto kstep = [&](u32x4 (&w)[UT], int ks, auto allowed) {
       const int kn = (ks + 1) & (KS - 1);
       const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);
+      if (PL && (ks & 3) == wave) {
+        __builtin_nontemporal_store(ah, reinterpret_cast<u32x4*>(dg_t + ks * (2 * gp::TILE_B) + pl_off));
+        __builtin_nontemporal_store(al, reinterpret_cast<u32x4*>(dg_t + ks * (2 * gp::TILE_B) + gp::TILE_B + pl_off));
+      }
       w_wait<decltype(allowed)::value, UT, RING_AG>(w);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -473,6 +509,17 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
   w_wait<0, UT, RING_AG>(w0);
   w_wait<0, UT, RING_AG>(w1);
   w_wait<0, UT, RING_AG>(w2);
+  if (PL) {   // dA_0: no product reads it, copy its tiles out of LDS
+    lds_barrier();
+    const unsigned char* da_s = smem3;   // buffer 0 & 1
+    char* dg_t = dgp.base + dgp.tile(bt, 0, 0, 0);
+    for (int ks = wave; ks < KS; ks += 4)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_nontemporal_store(
+            *reinterpret_cast<const u32x4*>(da_s + p * PLANE + r * ROWB + (((4 * ks + g) ^ r) << 4)),
+            reinterpret_cast<u32x4*>(dg_t + (ks * 2 + p) * gp::TILE_B + pl_off));
+  }
 
   // bias-gradient partials: sum over the 4 row groups (lanes r, r+16, r+32, r+48)
 #pragma unroll
@@ -488,34 +535,34 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
   }
 }
 
-template <int H>
+template <int H, bool PL>
 int run_fwd3(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B,
-             int T, hipStream_t stream) {
+             int T, gp::SeqPlanes hp, hipStream_t stream) {
   using C = RecCfg<H>;
   using R = Rec3Cfg<H>;
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL((pack_whh3_kernel<H, false>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3_fwd");
   static unsigned long long lds_done = 0;
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_fwd_kernel<H>), R::LDS_F, &lds_done, "lstm_rec3_fwd")) return rc;
-  hipLaunchKernelGGL(lstm_rec3_fwd_kernel<H>, dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_F, stream, G, cseq, hseq,
-                     hlast, clast, img, B, T);
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_fwd_kernel<H, PL>), R::LDS_F, &lds_done, "lstm_rec3_fwd")) return rc;
+  hipLaunchKernelGGL((lstm_rec3_fwd_kernel<H, PL>), dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_F, stream, G, cseq, hseq,
+                     hlast, clast, img, B, T, hp);
   VTS_CHECK_LAUNCH("lstm_rec3_fwd");
   return VTS_OK;
 }
 
-template <int H>
+template <int H, bool PL>
 int run_bwd3(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
-             float* dbpart, const float* W_hh, float* Wp, int B, int T, hipStream_t stream) {
+             float* dbpart, const float* W_hh, float* Wp, int B, int T, gp::SeqPlanes dgp, hipStream_t stream) {
   using C = RecCfg<H>;
   using R = Rec3Cfg<H>;
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL((pack_whh3_kernel<H, true>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3_bwd");
   static unsigned long long lds_done = 0;
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_bwd_kernel<H>), R::LDS_B, &lds_done, "lstm_rec3_bwd")) return rc;
-  hipLaunchKernelGGL(lstm_rec3_bwd_kernel<H>, dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_B, stream, G, cseq, dhseq,
-                     dhlast, dclast, dbpart, img, B, T);
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_bwd_kernel<H, PL>), R::LDS_B, &lds_done, "lstm_rec3_bwd")) return rc;
+  hipLaunchKernelGGL((lstm_rec3_bwd_kernel<H, PL>), dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_B, stream, G, cseq, dhseq,
+                     dhlast, dclast, dbpart, img, B, T, dgp);
   VTS_CHECK_LAUNCH("lstm_rec3_bwd");
   return VTS_OK;
 }
@@ -524,23 +571,37 @@ int run_bwd3(float* G, const float* cseq, const float* dhseq, const float* dhlas
 
 bool vts_lstm_rec3_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
+// h_planes / dg_planes (hidden 256 only): plane outputs as described at the kernels; null = the fp32 outputs only
 int vts_lstm_rec3_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
-                      int B, int T, int H, hipStream_t stream) {
+                      int B, int T, int H, void* h_planes, hipStream_t stream) {
+  const gp::SeqPlanes none{nullptr, 0, 0, 0};
+  if (h_planes != nullptr) {
+    if (H != 256) { vts_set_error("lstm bf16x3 recurrence: plane output needs hidden size 256"); return VTS_ERR_UNSUPPORTED; }
+    return run_fwd3<256, true>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T,
+                               gp::SeqPlanes{reinterpret_cast<char*>(h_planes), 8, T + 1, 1}, stream);
+  }
   switch (H) {
-    case 64: return run_fwd3<64>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
-    case 128: return run_fwd3<128>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
-    case 256: return run_fwd3<256>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, stream);
+    case 64: return run_fwd3<64, false>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, none, stream);
+    case 128: return run_fwd3<128, false>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, none, stream);
+    case 256: return run_fwd3<256, false>(G, cseq, hseq, hlast, clast, W_hh, Wp, B, T, none, stream);
   }
   vts_set_error("lstm bf16x3 recurrence: hidden size %d not supported (64, 128, 256)", H);
   return VTS_ERR_UNSUPPORTED;
 }
 
 int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
-                      float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream) {
+                      float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, void* dg_planes,
+                      hipStream_t stream) {
+  const gp::SeqPlanes none{nullptr, 0, 0, 0};
+  if (dg_planes != nullptr) {
+    if (H != 256) { vts_set_error("lstm bf16x3 recurrence: plane output needs hidden size 256"); return VTS_ERR_UNSUPPORTED; }
+    return run_bwd3<256, true>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T,
+                               gp::SeqPlanes{reinterpret_cast<char*>(dg_planes), 32, T, 0}, stream);
+  }
   switch (H) {
-    case 64: return run_bwd3<64>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
-    case 128: return run_bwd3<128>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
-    case 256: return run_bwd3<256>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, stream);
+    case 64: return run_bwd3<64, false>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, none, stream);
+    case 128: return run_bwd3<128, false>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, none, stream);
+    case 256: return run_bwd3<256, false>(G, cseq, dhseq, dhlast, dclast, dbpart, W_hh, Wp, B, T, none, stream);
   }
   vts_set_error("lstm bf16x3 recurrence: hidden size %d not supported (64, 128, 256)", H);
   return VTS_ERR_UNSUPPORTED;

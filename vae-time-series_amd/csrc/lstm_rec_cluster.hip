@@ -16,6 +16,7 @@
 // when the whole grid fits on the device at one workgroup per CU) the kernels leave with an error word set and
 // NaN in the last step of the h sequence and in the final states, which turns the step's loss into NaN.
 #include "lstm_rec_common.h"
+#include "gemm_planes.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -84,7 +85,7 @@ typedef unsigned bvec4 __attribute__((vector_size(16)));
 __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
     float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
     float* __restrict__ clast, const u32x4* __restrict__ Wp, u64* __restrict__ xchg, unsigned* __restrict__ flags,
-    unsigned* __restrict__ err, int T, int nclusters, int spin_limit, int mute_member) {
+    unsigned* __restrict__ err, int T, int nclusters, int spin_limit, int mute_member, gp::SeqPlanes hp) {
   constexpr int JT = CH / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smemc[];
   __shared__ int dead;
@@ -119,6 +120,21 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 #pragma unroll
     for (int jl = 0; jl < 2; ++jl) cst[mt][jl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Plane output of the h sequence (hp.base != null; gemm_planes.h): member c owns column block c (its 32 hidden
+  // units) of every tile.  The fragments of k-step c that a step's product loads from the exchange buffer are the
+  // tiles of h_{t-1} for this wave's two window tiles, so they are stored as they are used; the last step's h is
+  // copied out of the staging planes at the end, and slot 0 (the zero initial state) is cleared here.
+  const bool planes = hp.base != nullptr;
+  const unsigned pl_off = gp::slot(g, r) * 16;
+  auto hp_tile = [&](int mt, int t, int p) -> char* {
+    return hp.base + hp.tile((long)q * 8 + 2 * wave + mt, t, c, p);
+  };
+  if (planes) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<u32x4*>(hp_tile(i >> 1, -1, i & 1) + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
   // gate block (tile16) of batch tile bt, step t, column tile (gate, hidden tile jt)
   auto gblock = [&](int mt, int t, int gate, int jl) -> long {
     const long bt = (long)q * 8 + 2 * wave + mt;
@@ -147,8 +163,10 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
     const long bt = (long)q * 8 + 2 * wave + mt;
     const int jt = 2 * c + jl;
     if (what == 0) {
+      if (hseq != nullptr) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) hseq[((bt * 16 + 4 * g + reg) * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
+        for (int reg = 0; reg < 4; ++reg) hseq[((bt * 16 + 4 * g + reg) * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
+      }
     } else if (what == 3) {
       st_bulk(cseq + ((bt * T + t) * JT + jt) * 256 + lane * 4, cst[mt][jl]);
     } else {
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const long b = bt * 16 + 4 * g + reg;
-          hseq[(b * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
+          if (hseq != nullptr) hseq[(b * T + t) * CH + jt * 16 + r] = hv[mt][jl][reg];
           if (t == T - 1) {
             if (hlast != nullptr) hlast[b * CH + jt * 16 + r] = hv[mt][jl][reg];
             if (clast != nullptr) clast[b * CH + jt * 16 + r] = cst[mt][jl][reg];
@@ -264,6 +282,13 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
         // fragments two k-steps ahead, two blocks of the next step's gates and two sixteenths of the previous
         // step's bulk stores (gates, cells, h sequence; they read act, hv and cst, which the cell update
         // further down overwrites) per k-step.
+        if (ct == 1 && planes && ks == c) {      // tiles of h_{t-1}, column block c
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              *reinterpret_cast<u32x4*>(hp_tile(mt, t - 1, p) + pl_off) = a[ks % 3][mt][p];
+        }
         if (ct == 2) load_g_part(tnext, ks);     // the last step re-reads its own blocks: no branch in the product
         if (ct == 4) store_part(t - 1, 2 * ks);
         if (ct == 6) store_part(t - 1, 2 * ks + 1);
@@ -329,6 +354,16 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
     STAMP(4);
   }
   if (!dead) bulk_store(T - 1);
+  if (!dead && planes) {
+    // h_{T-1} from the staging planes: each wave reads back only rows it wrote itself (LDS operations of a wave
+    // execute in order)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        *reinterpret_cast<u32x4*>(hp_tile(mt, T - 1, p) + pl_off) =
+            *reinterpret_cast<const u32x4*>(stage + p * S_PLANE + ((2 * wave + mt) * 16 + r) * 64 + g * 16);
+  }
   if (dead) {
     // a peer never published: besides the error word, poison what the layers above read (last step of the h
     // sequence, final states), so that the loss of such a step is NaN instead of a plausible number
@@ -341,7 +376,7 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
         for (int reg = 0; reg < 4; ++reg) {
           const long b = ((long)q * 8 + 2 * wave + mt) * 16 + 4 * g + reg;
           const int col = (2 * c + jl) * 16 + r;
-          hseq[(b * T + T - 1) * CH + col] = poison;
+          if (hseq != nullptr) hseq[(b * T + T - 1) * CH + col] = poison;
           if (hlast != nullptr) hlast[b * CH + col] = poison;
           if (clast != nullptr) clast[b * CH + col] = poison;
         }
@@ -370,7 +405,7 @@ size_t vts_lstm_rec3c_xchg_bytes(int B) { return (size_t)(B / CROWS) * X_CLUSTER
 size_t vts_lstm_rec3c_flag_bytes(int B) { return ((size_t)(B / CROWS) * NC + 1) * FLAG_STRIDE * sizeof(unsigned); }
 
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
-                       void* xws, void* fws, int B, int T, hipStream_t stream) {
+                       void* xws, void* fws, int B, int T, void* h_planes, hipStream_t stream) {
   const int nclusters = B / CROWS;
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL(pack_whh3c_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img);
@@ -393,7 +428,7 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
   }
   hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(64 * vts_cdiv(nclusters, 8)), dim3(256), C_LDS, stream, G, cseq, hseq,
                      hlast, clast, img, reinterpret_cast<unsigned long long*>(xws), flags, err, T, nclusters, spin_limit,
-                     mute_member);
+                     mute_member, gp::SeqPlanes{reinterpret_cast<char*>(h_planes), 8, T + 1, 1});
   VTS_CHECK_LAUNCH("lstm_rec3c_fwd");
   return VTS_OK;
 }

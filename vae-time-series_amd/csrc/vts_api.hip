@@ -54,12 +54,26 @@ int vts_attn_dropout_mask(unsigned long long seed, float drop_p, unsigned char* 
 bool vts_lstm_hidden_supported(int H);
 bool vts_lstm_rec3_supported(int H);
 bool vts_lstm_rec3c_usable(int B, int T, int H);
+bool vts_planes_usable(long B, long T, long H);
+int vts_planes_fpad(long F);
+size_t vts_planes_seq_bytes(long B, long T, long F, int with_zero_slot);
+size_t vts_planes_weight_bytes(long rows, long K);
+size_t vts_planes_wgrad_slab_bytes(long B, long T, long F, long H);
+int vts_planes_from_rows(const float* x, void* planes, long B, long T, long C, hipStream_t st);
+int vts_planes_zero_slot0(void* planes, long B, long T, long F, hipStream_t st);
+int vts_planes_inproj(const void* s_planes, int a_zero_slot, const float* w_ih, const float* b_ih, const float* b_hh,
+                      float* gates, void* wplanes, long B, long T, long Cin, long H, hipStream_t st);
+int vts_planes_dgrad(const void* dg_planes, const float* w_ih, float* dx_t16, void* wplanes, long B, long T, long Cin,
+                     long H, hipStream_t st);
+int vts_planes_wgrad(const void* dg_planes, const void* s_planes, int x_zero_slot, const void* h_planes, float* dw_ih,
+                     float* dw_hh, int accumulate, float* slabs, long B, long T, long F, long H, hipStream_t st);
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
-                       void* xws, void* fws, int B, int T, hipStream_t stream);
+                       void* xws, void* fws, int B, int T, void* h_planes, hipStream_t stream);
 int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
-                      float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream);
+                      float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, void* dg_planes,
+                      hipStream_t stream);
 int vts_lstm_rec3_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
-                      int B, int T, int H, hipStream_t stream);
+                      int B, int T, int H, void* h_planes, hipStream_t stream);
 int vts_lstm_rec_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B, int T,
                      int H, hipStream_t stream);
 int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
@@ -214,13 +228,13 @@ int vts_lstm_inproj_fwd(const float* x, const float* w_ih, const float* b_ih, co
                          reinterpret_cast<hipStream_t>(stream));
 }
 
-int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_last, float* c_last, const float* w_hh,
-                           void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
-                           vts_stream_t stream) {
+static int recurrent_fwd_impl(float* gates, float* cells, float* hseq, float* h_last, float* c_last, const float* w_hh,
+                              void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
+                              void* h_planes, vts_stream_t stream) {
   VTS_MODE_CHECK(dtype_mode);
   VTS_RC(lstm_check(B, T, 1, H));
-  VTS_REQUIRE(gates && cells && hseq && w_hh && workspace, "lstm_recurrent_fwd: null pointer");
-  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(hseq) && vts_aligned16(workspace) &&
+  VTS_REQUIRE(gates && cells && (hseq || h_planes) && w_hh && workspace, "lstm_recurrent_fwd: null pointer");
+  VTS_REQUIRE(vts_aligned16(gates) && vts_aligned16(cells) && (!hseq || vts_aligned16(hseq)) && vts_aligned16(workspace) &&
                   (!h_last || vts_aligned16(h_last)),
               "lstm_recurrent_fwd: gates, cells, hseq, h_last and workspace must be 16-byte aligned");
   VTS_REQUIRE(workspace_bytes >= vts_lstm_recurrent_workspace_bytes(B, T, H),
@@ -234,20 +248,29 @@ int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_las
     char* fws = ws + rec_ws_pack_bytes(H);
     char* xws = fws + rec_ws_dbpart_bytes(B, H);
     return vts_lstm_rec3c_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), xws, fws,
-                              (int)B, (int)T, reinterpret_cast<hipStream_t>(stream));
+                              (int)B, (int)T, h_planes, reinterpret_cast<hipStream_t>(stream));
   }
   // bf16x3 recurrence for the hidden sizes it is built for; smaller ones stay on the fp32 kernel
   if (dtype_mode == 1 && vts_lstm_rec3_supported((int)H))
     return vts_lstm_rec3_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), (int)B,
-                             (int)T, (int)H, reinterpret_cast<hipStream_t>(stream));
+                             (int)T, (int)H, h_planes, reinterpret_cast<hipStream_t>(stream));
+  VTS_REQUIRE(!h_planes, "lstm_recurrent_fwd: plane output needs dtype_mode 1");
   return vts_lstm_rec_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), (int)B,
                           (int)T, (int)H, reinterpret_cast<hipStream_t>(stream));
 }
 
-int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
-                           const float* dc_last, const float* w_hh, float* db_ih, float* db_hh, int accumulate,
+int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_last, float* c_last, const float* w_hh,
                            void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
                            vts_stream_t stream) {
+  VTS_REQUIRE(hseq, "lstm_recurrent_fwd: null pointer");
+  return recurrent_fwd_impl(gates, cells, hseq, h_last, c_last, w_hh, workspace, workspace_bytes, B, T, H, dtype_mode,
+                            nullptr, stream);
+}
+
+static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
+                              const float* dc_last, const float* w_hh, float* db_ih, float* db_hh, int accumulate,
+                              void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
+                              void* dg_planes, vts_stream_t stream) {
   VTS_MODE_CHECK(dtype_mode);
   VTS_RC(lstm_check(B, T, 1, H));
   VTS_REQUIRE(gates && cells && w_hh && workspace, "lstm_recurrent_bwd: null pointer");
@@ -268,12 +291,110 @@ int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq
     float* seed_c = dc_last ? reinterpret_cast<float*>(seed + rec_ws_seed_bytes(B, H)) : nullptr;
     if (seed_h) VTS_RC(vts_ew_tile16_convert(dh_last, seed_h, (int)B, 1, (int)H, 0, st));
     if (seed_c) VTS_RC(vts_ew_tile16_convert(dc_last, seed_c, (int)B, 1, (int)H, 0, st));
-    VTS_RC(vts_lstm_rec3_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
-  } else
+    VTS_RC(vts_lstm_rec3_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, (int)B, (int)T, (int)H,
+                             dg_planes, st));
+  } else {
+    VTS_REQUIRE(!dg_planes, "lstm_recurrent_bwd: plane output needs dtype_mode 1 and a hidden size of 256");
     VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
+  }
   if (db_ih) VTS_RC(vts_colsum_partials(dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));
   if (db_hh) VTS_RC(vts_colsum_partials(dbpart, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
   return VTS_OK;
+}
+
+int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
+                           const float* dc_last, const float* w_hh, float* db_ih, float* db_hh, int accumulate,
+                           void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
+                           vts_stream_t stream) {
+  return recurrent_bwd_impl(gates, cells, dh_seq_t16, dh_last, dc_last, w_hh, db_ih, db_hh, accumulate, workspace,
+                            workspace_bytes, B, T, H, dtype_mode, nullptr, stream);
+}
+
+// ---- the layer's products over bf16 plane operands (csrc/lstm_planes.hip, csrc/gemm_planes.h) ----
+int vts_lstm_planes_supported(int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode) {
+  static const bool on = [] { const char* e = getenv("VTS_LSTM_PLANES"); return !(e && e[0] == '0'); }();
+  if (!on || dtype_mode != 1 || Cin <= 0 || !fits_int(pad16(B) * T * 4 * H / 16)) return 0;
+  return vts_planes_usable((long)B, (long)T, (long)H) ? 1 : 0;
+}
+size_t vts_lstm_planes_bytes(int64_t B, int64_t T, int64_t F, int is_hseq) {
+  return vts_planes_seq_bytes((long)B, (long)T, (long)F, is_hseq ? 1 : 0);
+}
+size_t vts_lstm_planes_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H) {
+  const size_t w1 = vts_planes_weight_bytes(4 * H, Cin), w2 = vts_planes_weight_bytes(Cin, 4 * H);
+  const size_t w = w1 > w2 ? w1 : w2, sl = vts_planes_wgrad_slab_bytes((long)B, (long)T, (long)Cin, (long)H);
+  return round256(w > sl ? w : sl) + 256;
+}
+#define VTS_PLANES_CHECK(what)                                                                         \
+  VTS_MODE_CHECK(dtype_mode);                                                                          \
+  VTS_RC(lstm_check(B, T, Cin, H));                                                                    \
+  if (!vts_lstm_planes_supported(B, T, Cin, H, dtype_mode)) {                                          \
+    vts_set_error(what ": plane operands are not planned for B %ld, T %ld, H %ld, mode %d (see "       \
+                  "vts_lstm_planes_supported)", (long)B, (long)T, (long)H, dtype_mode);                \
+    return VTS_ERR_UNSUPPORTED;                                                                        \
+  }
+
+int vts_lstm_planes_from_rows(const float* x, void* x_planes, int64_t B, int64_t T, int64_t Cin, int64_t H,
+                              int dtype_mode, vts_stream_t stream) {
+  VTS_PLANES_CHECK("lstm_planes_from_rows");
+  VTS_REQUIRE(x && x_planes && vts_aligned16(x_planes), "lstm_planes_from_rows: null or misaligned pointer");
+  return vts_planes_from_rows(x, x_planes, (long)B, (long)T, (long)Cin, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_lstm_inproj_fwd_planes(const void* x_planes, int x_is_hseq, const float* w_ih, const float* b_ih,
+                               const float* b_hh, float* gates, void* workspace, size_t workspace_bytes, int64_t B,
+                               int64_t T, int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream) {
+  VTS_PLANES_CHECK("lstm_inproj_fwd_planes");
+  VTS_REQUIRE(x_planes && w_ih && b_ih && b_hh && gates && workspace, "lstm_inproj_fwd_planes: null pointer");
+  VTS_REQUIRE(vts_aligned16(x_planes) && vts_aligned16(gates) && vts_aligned16(workspace), "lstm_inproj_fwd_planes: 16-byte alignment");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_planes_workspace_bytes(B, T, Cin, H), "lstm_inproj_fwd_planes: workspace %zu B too small", workspace_bytes);
+  return vts_planes_inproj(x_planes, x_is_hseq, w_ih, b_ih, b_hh, gates, workspace, (long)B, (long)T, (long)Cin, (long)H,
+                           reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_lstm_recurrent_fwd_planes(float* gates, float* cells, float* hseq, void* h_planes, float* h_last, float* c_last,
+                                  const float* w_hh, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
+                                  int64_t H, int dtype_mode, vts_stream_t stream) {
+  const int64_t Cin = H;
+  VTS_PLANES_CHECK("lstm_recurrent_fwd_planes");
+  VTS_REQUIRE(h_planes && vts_aligned16(h_planes), "lstm_recurrent_fwd_planes: null or misaligned h_planes");
+  return recurrent_fwd_impl(gates, cells, hseq, h_last, c_last, w_hh, workspace, workspace_bytes, B, T, H, dtype_mode,
+                            h_planes, stream);
+}
+
+int vts_lstm_recurrent_bwd_planes(const float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
+                                  const float* dc_last, const float* w_hh, void* dg_planes, float* db_ih, float* db_hh,
+                                  int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
+                                  int64_t H, int dtype_mode, vts_stream_t stream) {
+  const int64_t Cin = H;
+  VTS_PLANES_CHECK("lstm_recurrent_bwd_planes");
+  VTS_REQUIRE(dg_planes && vts_aligned16(dg_planes), "lstm_recurrent_bwd_planes: null or misaligned dg_planes");
+  return recurrent_bwd_impl(const_cast<float*>(gates), cells, dh_seq_t16, dh_last, dc_last, w_hh, db_ih, db_hh, accumulate,
+                            workspace, workspace_bytes, B, T, H, dtype_mode, dg_planes, stream);
+}
+
+int vts_lstm_dgrad_planes(const void* dg_planes, const float* w_ih, float* dx_t16, void* workspace,
+                          size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode,
+                          vts_stream_t stream) {
+  VTS_PLANES_CHECK("lstm_dgrad_planes");
+  VTS_REQUIRE(dg_planes && w_ih && dx_t16 && workspace, "lstm_dgrad_planes: null pointer");
+  VTS_REQUIRE((Cin % 256) == 0, "lstm_dgrad_planes: needs Cin %% 256 == 0 (got %ld)", (long)Cin);
+  VTS_REQUIRE(vts_aligned16(dg_planes) && vts_aligned16(dx_t16) && vts_aligned16(workspace), "lstm_dgrad_planes: 16-byte alignment");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_planes_workspace_bytes(B, T, Cin, H), "lstm_dgrad_planes: workspace %zu B too small", workspace_bytes);
+  return vts_planes_dgrad(dg_planes, w_ih, dx_t16, workspace, (long)B, (long)T, (long)Cin, (long)H,
+                          reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_lstm_wgrad_planes(const void* dg_planes, const void* x_planes, int x_is_hseq, const void* h_planes, float* dw_ih,
+                          float* dw_hh, int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
+                          int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream) {
+  VTS_PLANES_CHECK("lstm_wgrad_planes");
+  VTS_REQUIRE(dg_planes && x_planes && h_planes && dw_ih && dw_hh && workspace, "lstm_wgrad_planes: null pointer");
+  VTS_REQUIRE(vts_aligned16(dg_planes) && vts_aligned16(x_planes) && vts_aligned16(h_planes) && vts_aligned16(workspace),
+              "lstm_wgrad_planes: 16-byte alignment");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_planes_workspace_bytes(B, T, Cin, H), "lstm_wgrad_planes: workspace %zu B too small", workspace_bytes);
+  return vts_planes_wgrad(dg_planes, x_planes, x_is_hseq, h_planes, dw_ih, dw_hh, accumulate,
+                          reinterpret_cast<float*>(workspace), (long)B, (long)T, (long)Cin, (long)H,
+                          reinterpret_cast<hipStream_t>(stream));
 }
 
 int vts_lstm_dgrad(const float* dgates, const float* w_ih, float* dx_t16, int64_t B, int64_t T, int64_t Cin,

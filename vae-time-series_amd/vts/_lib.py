@@ -41,6 +41,17 @@ SIGNATURES = {
     "vts_lstm_wgrad": (_int, [_ptr, _ptr, _int, _ptr, _int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_wgrad_pair_supported": (_int, [_i64, _i64, _i64, _i64, _int]),
     "vts_lstm_wgrad_pair": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_planes_supported": (_int, [_i64, _i64, _i64, _i64, _int]),
+    "vts_lstm_planes_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "vts_lstm_planes_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "vts_lstm_planes_from_rows": (_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_inproj_fwd_planes": (_int, [_ptr, _int, _ptr, _ptr, _ptr, _ptr, _ptr, _sz, _i64, _i64, _i64, _i64, _int,
+                                          _ptr]),
+    "vts_lstm_recurrent_fwd_planes": (_int, [_ptr] * 7 + [_ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_recurrent_bwd_planes": (_int, [_ptr] * 9 + [_int, _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_dgrad_planes": (_int, [_ptr, _ptr, _ptr, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "vts_lstm_wgrad_planes": (_int, [_ptr, _ptr, _int, _ptr, _ptr, _ptr, _int, _ptr, _sz, _i64, _i64, _i64, _i64,
+                                     _int, _ptr]),
     "vts_tile16_convert": (_int, [_ptr, _ptr, _i64, _i64, _i64, _int, _ptr]),
     "vts_linear_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _f32, _ptr, _int, _ptr]),
     "vts_linear_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -45,110 +45,179 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------- LSTM
-class _LSTMStack(torch.autograd.Function):
-    """All layers of nn.LSTM(batch_first=True), zero initial state.
-    Returns (output [B,T,H], h_n [layers,B,H], c_n [layers,B,H])."""
+class _LayerCfg:
+    """Static facts of one layer of a stack, shared by its forward and backward."""
+
+    def __init__(self, B, T, cin, H, first, last, planes, need_seq, mode):
+        self.B, self.T, self.cin, self.H = B, T, cin, H
+        self.first, self.last, self.planes, self.need_seq, self.mode = first, last, planes, need_seq, mode
+        self.Bp = (B + 15) // 16 * 16
+
+
+class _LSTMLayer(torch.autograd.Function):
+    """One layer of nn.LSTM(batch_first=True), zero initial state: (activation, h_last [B,H], c_last [B,H]).
+
+    One autograd node per layer, so a layer's weight gradients are final (and a data-parallel trainer's hooks can
+    send them) while the layers below are still in their backward pass.
+
+    What travels between the layers of a stack is private to them.  Forward: the h sequence, either fp32 rows
+    [Bp, T, H] (Bp = B rounded up to 16) or, on the plane path (vts_lstm_planes_supported), the bf16 head/tail
+    planes of csrc/gemm_planes.h viewed as a float tensor.  Backward: the gradient w.r.t. that sequence in the
+    kernels' tile16 layout, in a tensor of the activation's shape (autograd only checks the shape).  The last
+    layer returns ordinary rows [B, T, H] (an empty tensor if the caller does not want the sequence) and takes an
+    ordinary gradient; the first layer takes ordinary rows."""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, num_layers: int, *weights: torch.Tensor):
-        _need_gpu(x)
+    def forward(ctx, inp, w_ih, w_hh, b_ih, b_hh, cfg: _LayerCfg):
         lib = L.load()
-        x = x.contiguous()
-        B, T, C0 = x.shape
-        H = weights[1].shape[1]
-        dev = x.device
-        h_n = torch.empty(num_layers, B, H, device=dev, dtype=torch.float32)
-        c_n = torch.empty(num_layers, B, H, device=dev, dtype=torch.float32)
-        saved: List[torch.Tensor] = []
-        inp = x
-        for k in range(num_layers):
-            w_ih, w_hh, b_ih, b_hh = [w.contiguous() for w in weights[4 * k:4 * k + 4]]
-            cin = inp.shape[2]
-            gates = L.workspace(lib.vts_lstm_gates_bytes(B, T, H), dev)
-            cells = L.workspace(lib.vts_lstm_cells_bytes(B, T, H), dev)
-            hseq = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-            ws_bytes = lib.vts_lstm_recurrent_workspace_bytes(B, T, H)
-            ws = L.workspace(ws_bytes, dev)
-            st = L.stream()
-            L.check(L.timer.call("lstm_inproj_fwd", lib.vts_lstm_inproj_fwd, L.ptr(inp), L.ptr(w_ih), L.ptr(b_ih),
-                                 L.ptr(b_hh), L.wptr(gates), B, T, cin, H, _MODE, st), "vts_lstm_inproj_fwd")
+        B, T, cin, H, mode = cfg.B, cfg.T, cfg.cin, cfg.H, cfg.mode
+        dev = inp.device
+        w_ih, w_hh, b_ih, b_hh = w_ih.contiguous(), w_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()
+        gates = L.workspace(lib.vts_lstm_gates_bytes(B, T, H), dev)
+        cells = L.workspace(lib.vts_lstm_cells_bytes(B, T, H), dev)
+        h_last = torch.empty(B, H, device=dev, dtype=torch.float32)
+        c_last = torch.empty(B, H, device=dev, dtype=torch.float32)
+        ws_bytes = lib.vts_lstm_recurrent_workspace_bytes(B, T, H)
+        ws = L.workspace(ws_bytes, dev)
+        st = L.stream()
+        want_rows = (cfg.last and cfg.need_seq) or not cfg.planes
+        hseq = None
+        if want_rows:
+            hseq = torch.empty(B if cfg.last else cfg.Bp, T, H, device=dev, dtype=torch.float32)
+        if cfg.planes:
+            if cfg.first:
+                xp = L.workspace(lib.vts_lstm_planes_bytes(B, T, cin, 0), dev)
+                L.check(L.timer.call("lstm_x_to_planes", lib.vts_lstm_planes_from_rows, L.ptr(inp), L.wptr(xp), B, T, cin,
+                                     H, mode, st), "vts_lstm_planes_from_rows")
+            else:
+                xp = inp
+            pws_bytes = lib.vts_lstm_planes_workspace_bytes(B, T, cin, H)
+            pws = L.workspace(pws_bytes, dev)
+            L.check(L.timer.call("lstm_inproj_fwd", lib.vts_lstm_inproj_fwd_planes, L.wptr(xp), 0 if cfg.first else 1,
+                                 L.ptr(w_ih), L.ptr(b_ih), L.ptr(b_hh), L.wptr(gates), L.wptr(pws), pws_bytes, B, T, cin,
+                                 H, mode, st), "vts_lstm_inproj_fwd_planes")
+            hp = torch.empty(lib.vts_lstm_planes_bytes(B, T, H, 1) // 4, device=dev, dtype=torch.float32)
+            L.check(L.timer.call("lstm_recurrent_fwd", lib.vts_lstm_recurrent_fwd_planes, L.wptr(gates), L.wptr(cells),
+                                 L.ptr(hseq), L.wptr(hp), L.ptr(h_last), L.ptr(c_last), L.ptr(w_hh), L.wptr(ws), ws_bytes,
+                                 B, T, H, mode, st), "vts_lstm_recurrent_fwd_planes")
+            ctx.save_for_backward(xp, gates, cells, hp, w_ih, w_hh)
+        else:
+            x_rows = inp if cfg.first else inp   # rows either way; only the first B windows of a padded tensor are read
+            L.check(L.timer.call("lstm_inproj_fwd", lib.vts_lstm_inproj_fwd, L.ptr(x_rows), L.ptr(w_ih), L.ptr(b_ih),
+                                 L.ptr(b_hh), L.wptr(gates), B, T, cin, H, mode, st), "vts_lstm_inproj_fwd")
             L.check(L.timer.call("lstm_recurrent_fwd", lib.vts_lstm_recurrent_fwd, L.wptr(gates), L.wptr(cells),
-                                 L.ptr(hseq), L.ptr(h_n[k]), L.ptr(c_n[k]), L.ptr(w_hh), L.wptr(ws), ws_bytes,
-                                 B, T, H, _MODE, st), "vts_lstm_recurrent_fwd")
-            saved += [inp, gates, cells, hseq]
-            inp = hseq
-        ctx.num_layers = num_layers
-        ctx.dims = (B, T, C0, H)
-        ctx.save_for_backward(*saved, *weights)
+                                 L.ptr(hseq), L.ptr(h_last), L.ptr(c_last), L.ptr(w_hh), L.wptr(ws), ws_bytes,
+                                 B, T, H, mode, st), "vts_lstm_recurrent_fwd")
+            hp = None
+            ctx.save_for_backward(x_rows, gates, cells, hseq, w_ih, w_hh)
+        ctx.cfg = cfg
+        ctx.ran = False
         ctx.set_materialize_grads(False)
-        return inp, h_n, c_n
+        if cfg.last:
+            act = hseq if hseq is not None else torch.empty(0, device=dev, dtype=torch.float32)
+        else:
+            act = hp if cfg.planes else hseq
+        return act, h_last, c_last
 
     @staticmethod
-    def backward(ctx, g_out, g_hn, g_cn):
+    def backward(ctx, g_act, g_h, g_c):
         lib = L.load()
-        nl = ctx.num_layers
-        B, T, C0, H = ctx.dims
-        tensors = ctx.saved_tensors
-        saved, weights = tensors[:4 * nl], tensors[4 * nl:]
-        dev = saved[0].device
-        grads: List[Optional[torch.Tensor]] = [None] * (4 * nl)
+        cfg = ctx.cfg
+        B, T, cin, H, mode = cfg.B, cfg.T, cfg.cin, cfg.H, cfg.mode
+        xin, gates, cells, hs, w_ih, w_hh = ctx.saved_tensors
+        dev = gates.device
+        if ctx.ran and not cfg.planes:
+            raise RuntimeError("vts LSTM: a second backward pass over the same forward is not supported (the first "
+                               "one turned the saved gate activations into gate gradients in place)")
+        ctx.ran = True
+        st = L.stream()
         dh_seq = None
-        if g_out is not None:
-            dh_seq = L.workspace(lib.vts_lstm_seqgrad_bytes(B, T, H), dev)
-            L.check(lib.vts_tile16_convert(L.ptr(g_out.contiguous()), L.wptr(dh_seq), B, T, H, 0, L.stream()),
-                    "vts_tile16_convert")
-        dx0 = None
-        for k in reversed(range(nl)):
-            inp, gates, cells, hseq = saved[4 * k:4 * k + 4]
-            w_ih, w_hh = weights[4 * k].contiguous(), weights[4 * k + 1].contiguous()
-            cin = inp.shape[2]
-            need_dx = (k > 0) or ctx.needs_input_grad[0]
-            if need_dx and cin % 16 != 0:
-                raise NotImplementedError("gradient w.r.t. the LSTM input needs input_size % 16 == 0")
-            dx = L.workspace(lib.vts_lstm_seqgrad_bytes(B, T, cin), dev) if need_dx else None
-            dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
-            db_ih = torch.empty(4 * H, device=dev, dtype=torch.float32)
-            db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
-            dh_last = _c(g_hn[k]) if g_hn is not None else None
-            dc_last = _c(g_cn[k]) if g_cn is not None else None
-            st = L.stream()
-            ws_bytes = lib.vts_lstm_recurrent_workspace_bytes(B, T, H)
-            ws = L.workspace(ws_bytes, dev)
+        if g_act is not None and g_act.numel() > 0:
+            if cfg.last:      # ordinary rows from outside the stack
+                dh_seq = L.workspace(lib.vts_lstm_seqgrad_bytes(B, T, H), dev)
+                L.check(lib.vts_tile16_convert(L.ptr(g_act.contiguous()), L.wptr(dh_seq), B, T, H, 0, st),
+                        "vts_tile16_convert")
+            else:             # tile16 from the layer above
+                dh_seq = g_act
+        need_dx = (not cfg.first) or ctx.needs_input_grad[0]
+        if need_dx and cin % 16 != 0:
+            raise NotImplementedError("gradient w.r.t. the LSTM input needs input_size % 16 == 0")
+        dx = None
+        if need_dx:
+            # shaped like the activation it is the gradient of (planes carry one more step slot than tile16 needs)
+            n = xin.numel() if not cfg.first else lib.vts_lstm_seqgrad_bytes(B, T, cin) // 4
+            dx = torch.empty(n, device=dev, dtype=torch.float32)
+        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        db_ih = torch.empty(4 * H, device=dev, dtype=torch.float32)
+        db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
+        dh_last = _c(g_h)
+        dc_last = _c(g_c)
+        ws_bytes = lib.vts_lstm_recurrent_workspace_bytes(B, T, H)
+        ws = L.workspace(ws_bytes, dev)
+        if cfg.planes:
+            dgp = L.workspace(lib.vts_lstm_planes_bytes(B, T, 4 * H, 0), dev)
+            L.check(L.timer.call("lstm_recurrent_bwd", lib.vts_lstm_recurrent_bwd_planes, L.wptr(gates), L.wptr(cells),
+                                 None if dh_seq is None else L.wptr(dh_seq), L.ptr(dh_last), L.ptr(dc_last), L.ptr(w_hh),
+                                 L.wptr(dgp), L.ptr(db_ih), L.ptr(db_hh), 0, L.wptr(ws), ws_bytes, B, T, H, mode, st),
+                    "vts_lstm_recurrent_bwd_planes")
+            pws_bytes = lib.vts_lstm_planes_workspace_bytes(B, T, cin, H)
+            pws = L.workspace(pws_bytes, dev)
+            if dx is not None:
+                L.check(L.timer.call("lstm_dgrad", lib.vts_lstm_dgrad_planes, L.wptr(dgp), L.ptr(w_ih), L.wptr(dx),
+                                     L.wptr(pws), pws_bytes, B, T, cin, H, mode, st), "vts_lstm_dgrad_planes")
+            L.check(L.timer.call("lstm_wgrad_pair", lib.vts_lstm_wgrad_planes, L.wptr(dgp), L.wptr(xin),
+                                 0 if cfg.first else 1, L.wptr(hs), L.ptr(dw_ih), L.ptr(dw_hh), 0, L.wptr(pws), pws_bytes,
+                                 B, T, cin, H, mode, st), "vts_lstm_wgrad_planes")
+        else:
             L.check(L.timer.call("lstm_recurrent_bwd", lib.vts_lstm_recurrent_bwd, L.wptr(gates), L.wptr(cells),
                                  None if dh_seq is None else L.wptr(dh_seq), L.ptr(dh_last), L.ptr(dc_last),
-                                 L.ptr(w_hh), L.ptr(db_ih), L.ptr(db_hh), 0, L.wptr(ws), ws_bytes, B, T, H, _MODE,
+                                 L.ptr(w_hh), L.ptr(db_ih), L.ptr(db_hh), 0, L.wptr(ws), ws_bytes, B, T, H, mode,
                                  st), "vts_lstm_recurrent_bwd")
             if dx is not None:
                 L.check(L.timer.call("lstm_dgrad", lib.vts_lstm_dgrad, L.wptr(gates), L.ptr(w_ih), L.wptr(dx),
-                                     B, T, cin, H, _MODE, st), "vts_lstm_dgrad")
+                                     B, T, cin, H, mode, st), "vts_lstm_dgrad")
             wg_bytes = max(lib.vts_lstm_wgrad_workspace_bytes(B, T, cin, H),
                            lib.vts_lstm_wgrad_workspace_bytes(B, T, H, H))
             wg = L.workspace(wg_bytes, dev)
-            if lib.vts_lstm_wgrad_pair_supported(B, T, cin, H, _MODE):
+            if lib.vts_lstm_wgrad_pair_supported(B, T, cin, H, mode):
                 # both weight gradients in one launch (the first 256 input columns ride with the recurrent product)
-                L.check(L.timer.call("lstm_wgrad_pair", lib.vts_lstm_wgrad_pair, L.wptr(gates), L.ptr(inp), L.ptr(hseq),
-                                     L.ptr(dw_ih), L.ptr(dw_hh), 0, L.wptr(wg), wg_bytes, B, T, cin, H, _MODE, st),
+                L.check(L.timer.call("lstm_wgrad_pair", lib.vts_lstm_wgrad_pair, L.wptr(gates), L.ptr(xin), L.ptr(hs),
+                                     L.ptr(dw_ih), L.ptr(dw_hh), 0, L.wptr(wg), wg_bytes, B, T, cin, H, mode, st),
                         "vts_lstm_wgrad_pair")
             else:
-                L.check(L.timer.call("lstm_wgrad_ih", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(inp), 0, L.ptr(dw_ih), 0,
-                                     L.wptr(wg), wg_bytes, B, T, cin, H, _MODE, st), "vts_lstm_wgrad")
-                L.check(L.timer.call("lstm_wgrad_hh", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(hseq), -1, L.ptr(dw_hh),
-                                     0, L.wptr(wg), wg_bytes, B, T, H, H, _MODE, st), "vts_lstm_wgrad")
-            grads[4 * k:4 * k + 4] = [dw_ih, dw_hh, db_ih, db_hh]
-            dh_seq = dx
-            if k == 0:
-                dx0 = dx
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty(B, T, C0, device=dev, dtype=torch.float32)
-            L.check(lib.vts_tile16_convert(L.ptr(gx), L.wptr(dx0), B, T, C0, 1, L.stream()), "vts_tile16_convert")
-        return (gx, None, *grads)
+                L.check(L.timer.call("lstm_wgrad_ih", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(xin), 0, L.ptr(dw_ih), 0,
+                                     L.wptr(wg), wg_bytes, B, T, cin, H, mode, st), "vts_lstm_wgrad")
+                L.check(L.timer.call("lstm_wgrad_hh", lib.vts_lstm_wgrad, L.wptr(gates), L.ptr(hs), -1, L.ptr(dw_hh),
+                                     0, L.wptr(wg), wg_bytes, B, T, H, H, mode, st), "vts_lstm_wgrad")
+        gin = None
+        if need_dx:
+            if cfg.first:
+                gin = torch.empty(B, T, cin, device=dev, dtype=torch.float32)
+                L.check(lib.vts_tile16_convert(L.ptr(gin), L.wptr(dx), B, T, cin, 1, st), "vts_tile16_convert")
+            else:
+                gin = dx.view(xin.shape)
+        return gin, dw_ih, dw_hh, db_ih, db_hh, None
 
 
-def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int
+def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int, need_output: bool = True
          ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(output, h_n, c_n) of a stacked batch-first LSTM; ``weights`` = [w_ih, w_hh, b_ih, b_hh] per layer."""
-    return _LSTMStack.apply(x, num_layers, *weights)
+    """(output, h_n, c_n) of a stacked batch-first LSTM; ``weights`` = [w_ih, w_hh, b_ih, b_hh] per layer.
+    need_output=False (callers that read only h_n, as the reference's encoders do: gaussian-lstm-DE.py:28) lets
+    the plane path skip the fp32 copy of the top layer's sequence; ``output`` is then an empty tensor."""
+    _need_gpu(x)
+    lib = L.load()
+    x = x.contiguous()
+    B, T, C0 = x.shape
+    H = weights[1].shape[1]
+    planes = bool(lib.vts_lstm_planes_supported(B, T, C0, H, _MODE)) and not (x.requires_grad and C0 % 256 != 0)
+    act = x
+    hs, cs = [], []
+    for k in range(num_layers):
+        cfg = _LayerCfg(B, T, C0 if k == 0 else H, H, k == 0, k == num_layers - 1, planes, need_output, _MODE)
+        act, h_last, c_last = _LSTMLayer.apply(act, *weights[4 * k:4 * k + 4], cfg)
+        hs.append(h_last)
+        cs.append(c_last)
+    return act, torch.stack(hs), torch.stack(cs)
 
 
 # ----------------------------------------------------------------------------------- Linear

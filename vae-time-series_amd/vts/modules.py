@@ -55,14 +55,17 @@ class LSTM(nn.Module):
                     getattr(self, f"bias_ih_l{k}"), getattr(self, f"bias_hh_l{k}")]
         return out
 
-    def forward(self, x: torch.Tensor, hx=None):
+    def forward(self, x: torch.Tensor, hx=None, need_output: bool = True):
+        """As nn.LSTM.forward.  need_output=False: the caller reads only (h_n, c_n) - the reference's encoders
+        do, e.g. gaussian-lstm-DE.py:28 - and `output` comes back as an empty tensor (saves writing the top
+        layer's fp32 sequence on the bench-sized path)."""
         if hx is not None:
             raise NotImplementedError("vts.LSTM: a non-zero initial state is not supported")
         if isinstance(x, nn.utils.rnn.PackedSequence):
             raise NotImplementedError("vts.LSTM: packed sequences are not supported")
         if x.dim() != 3 or x.shape[2] != self.input_size:
             raise ValueError(f"vts.LSTM: expected input [B, T, {self.input_size}], got {tuple(x.shape)}")
-        out, h_n, c_n = F.lstm(x, self.flat_weights(), self.num_layers)
+        out, h_n, c_n = F.lstm(x, self.flat_weights(), self.num_layers, need_output)
         return out, (h_n, c_n)
 
 
@@ -96,7 +99,7 @@ class GaussianEncoder(nn.Module):
         self.logvar_layer = Linear(lstm_output_dim, latent_dim)
 
     def forward(self, x):
-        _, (h_n, _) = self.lstm(x)
+        _, (h_n, _) = self.lstm(x, need_output=False)
         h = h_n[-1]
         return self.mean_layer(h), self.logvar_layer(h)
 
@@ -155,7 +158,7 @@ class DeepEncoder(nn.Module):
         self.gaussian_heads = gaussian_heads
 
     def forward(self, x, noise: Noise = None):
-        _, (h_n, _) = self.lstm(x)
+        _, (h_n, _) = self.lstm(x, need_output=False)
         h = self.layer_norm(h_n[-1])
         hidden = self.fc1(h, act=L.ACT_RELU)
         keep = _keep_mask(noise, "enc_keep", self.training, (hidden.shape[0], 64), hidden.device)
@@ -247,7 +250,7 @@ class ThreeComponentEncoder(DeepEncoder):
         self.logits_layer_zero = Linear(64, latent_dim)
 
     def forward(self, x, noise: Noise = None):
-        _, (h_n, _) = self.lstm(x)
+        _, (h_n, _) = self.lstm(x, need_output=False)
         h = self.layer_norm(h_n[-1])
         hidden = self.fc1(h, act=L.ACT_RELU)
         keep = _keep_mask(noise, "enc_keep", self.training, (hidden.shape[0], 64), hidden.device)
