@@ -74,6 +74,19 @@ def _linear(sd: State, name: str, x: Tensor) -> Tensor:
     return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
 
 
+# When a test sets this to a dict, every ReLU site stores which units were active (pre-activation > 0) under the
+# layer's name: the reference's gradient jumps wherever a unit changes sides, so a test that compares gradients
+# across implementations first checks that both saw the same pattern.
+RELU_TAPS: Optional[Dict[str, Tensor]] = None
+
+
+def _relu_linear(sd: State, name: str, x: Tensor) -> Tensor:
+    pre = _linear(sd, name, x)
+    if RELU_TAPS is not None:
+        RELU_TAPS[name] = (pre > 0).detach()
+    return F.relu(pre)
+
+
 def _dropout(x: Tensor, keep: Optional[Tensor]) -> Tensor:
     """nn.Dropout(0.3) with the Bernoulli keep-mask fed in; ``None`` = eval mode."""
     if keep is None:
@@ -94,8 +107,8 @@ def _trunk(sd: State, x: Tensor, enc_keep: Optional[Tensor], stock: bool) -> Ten
     h = lstm_last_hidden(sd, x, 3, stock=stock)
     h = F.layer_norm(h, (h.shape[1],), sd["encoder.layer_norm.weight"],
                      sd["encoder.layer_norm.bias"], 1e-5)
-    h = F.relu(_linear(sd, "encoder.fc1", h))
-    return _dropout(F.relu(_linear(sd, "encoder.fc2", h)), enc_keep)
+    h = _relu_linear(sd, "encoder.fc1", h)
+    return _dropout(_relu_linear(sd, "encoder.fc2", h), enc_keep)
 
 
 def encode_gpd(sd: State, x: Tensor, enc_keep: Optional[Tensor], stock: bool = True):
@@ -157,13 +170,13 @@ def mixture3_select(zg: Tensor, zp: Tensor, zb: Tensor, pi_params: Tensor, choic
 # ----------------------------------------------------------------------- decoders
 def decode_gaussian(sd: State, z: Tensor) -> Tensor:
     """gaussian-lstm-DE.py:42-45."""
-    return _linear(sd, "decoder.out", F.relu(_linear(sd, "decoder.dense1", z)))
+    return _linear(sd, "decoder.out", _relu_linear(sd, "decoder.dense1", z))
 
 
 def decode_deep(sd: State, z: Tensor, dec_keep: Optional[Tensor]) -> Tensor:
     """gpd-lstm-DE.py:44-47 ; mixture-vae-DE.py:80-83."""
-    z = F.relu(_linear(sd, "decoder.fc1", z))
-    z = _dropout(F.relu(_linear(sd, "decoder.fc2", z)), dec_keep)
+    z = _relu_linear(sd, "decoder.fc1", z)
+    z = _dropout(_relu_linear(sd, "decoder.fc2", z), dec_keep)
     return _linear(sd, "decoder.out", z)
 
 

@@ -13,8 +13,12 @@ Two tests.
 The LSTM stack alone under a smooth loss (sigmoid / tanh only): h_n, c_n and every LSTM parameter gradient at 1e-4
 (measured worst 1.3e-5); this is where the time of a step goes.
 
-The whole model step: loss at 1e-5; every gradient at 1e-4 with fp32 products; in bf16x3 mode the decoder's
-output layer (downstream of every ReLU) at 1e-4 and the other gradients at KINK_TOL = 2e-3.  The ReLU layers make the reference's own gradient discontinuous: at this size
+The whole model step: loss at 1e-5 and EVERY gradient at 1e-4 in both arithmetic modes, provided the ReLU units of
+the trunk and decoder were on the same side of zero in both implementations - which the test checks unit by unit
+(the oracle records its pattern, forward hooks read the HIP path's) and which holds for the draws used here.  Should
+a unit ever differ (a later change of rounding), the test names the flipped units and falls back to the bound a
+flip can cost: the decoder's output layer (downstream of every ReLU) still at 1e-4, the other gradients at
+KINK_TOL = 2e-3.  Why a flip matters: the ReLU layers make the reference's own gradient discontinuous: at this size
 2 to 3 million ReLU units see pre-activations that differ by ~1e-6 between any two evaluations of the forward
 pass, so about one unit per draw sits within that distance of zero, and one flipped unit moves its layer's bias
 gradient by 2e-4 of its norm (one window of 4096, undiluted) and the gradients upstream of it by up to 9e-4.
@@ -31,8 +35,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 B, T, C, H, LD = 4096, 96, 370, 256, 32
 THRESHOLD = 0.8          # |y| <= 0.8: a mixed normal / extreme mask on N(0, 1) targets
-SEED = 11
-KINK_TOL = 2e-3         # see the module docstring
+SEED = {"mixture": 11, "gpd": 11, "gaussian": 11}     # draws in which no ReLU unit changes sides (checked below)
+KINK_TOL = 2e-3         # fallback bound when one does: see the module docstring
+RELU_SITES = {"gaussian": [("decoder.dense1", None)],
+              "gpd": [("encoder.fc1", None), ("encoder.fc2", "enc_keep"), ("decoder.fc1", None), ("decoder.fc2", "dec_keep")]}
+RELU_SITES["mixture"] = RELU_SITES["gpd"]
 _CACHE = {}
 
 
@@ -80,13 +87,34 @@ def _case(kind):
             # keep the GPD shapes off the 1e-6 clamp, where the reference's own fp32 sampler gradient is noise
             sd["encoder.shape_layer_extreme.weight"] *= 0.25
             sd["encoder.shape_layer_extreme.bias"].fill_(0.5)
-        g = torch.Generator().manual_seed(SEED)
+        g = torch.Generator().manual_seed(SEED[kind])
         x = torch.randn(B, T, C, generator=g)
         y = torch.randn(B, 1, generator=g)
-        noise = R.draw_noise(kind, B, LD, seed=SEED + 1)
-        loss, _, grads = R.loss_and_grads(kind, sd, x, y, noise, threshold=THRESHOLD)
-        _CACHE[kind] = (sd, x, y, noise, loss, grads)
+        noise = R.draw_noise(kind, B, LD, seed=SEED[kind] + 1)
+        R.RELU_TAPS = {}
+        try:
+            loss, _, grads = R.loss_and_grads(kind, sd, x, y, noise, threshold=THRESHOLD)
+            taps = dict(R.RELU_TAPS)
+        finally:
+            R.RELU_TAPS = None
+        _CACHE[kind] = (sd, x, y, noise, loss, grads, taps)
     return _CACHE[kind]
+
+
+def _flipped_units(kind, model, taps_ref, noise, seen):
+    """ReLU units (layer, window, unit) that were active in one implementation and not in the other.  `seen` holds
+    the HIP layers' outputs (relu, or relu times the dropout keep mask / 0.7): a kept unit is active iff its output
+    is positive; dropped units pass no gradient on either side and are left out."""
+    flips = []
+    for name, keep_key in RELU_SITES[kind]:
+        active = seen[name].cpu() > 0
+        ref = taps_ref[name]
+        if keep_key is not None:
+            keep = noise[keep_key] > 0
+            active, ref = active & keep, ref & keep
+        for w, u in (active != ref).nonzero().tolist():
+            flips.append((name, w, u))
+    return flips
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
@@ -95,17 +123,26 @@ def test_bench_sized_step_matches_oracle(kind, mode):
     import vts
     assert torch.cuda.is_available(), "GPU tests need a ROCm device"
     dev = torch.device("cuda:0")
-    sd, x, y, noise, loss_ref, grads_ref = _case(kind)
+    sd, x, y, noise, loss_ref, grads_ref, taps_ref = _case(kind)
     vts.set_mode(mode)
+    seen, hooks = {}, []
     try:
         model = vts.build_model(kind, C, H, LD, 1, threshold=THRESHOLD).to(dev)
         model.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
         model.train()
+        for name, _ in RELU_SITES[kind]:
+            layer = model.get_submodule(name)
+            hooks.append(layer.register_forward_hook(lambda _m, _i, out, name=name: seen.__setitem__(name, out.detach())))
         loss = vts.train_step(model, None, x.to(dev), y.to(dev), {k: v.to(dev) for k, v in noise.items()})
         torch.cuda.synchronize()
     finally:
         vts.set_mode("f32")
+        for h in hooks:
+            h.remove()
     assert torch.isfinite(loss).item()
+    flips = _flipped_units(kind, model, taps_ref, noise, seen)
+    if flips:
+        print(f"{kind}/{mode}: {len(flips)} ReLU unit(s) on different sides of zero: {flips[:8]}")
     assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
     for name, p in model.named_parameters():
         ref = grads_ref[name]
@@ -114,9 +151,11 @@ def test_bench_sized_step_matches_oracle(kind, mode):
             assert (got - ref).abs().max().item() <= 1e-6 * abs(loss_ref.item())
             continue
         rel = _l2_rel(got, ref)
-        # fp32 products: no flip in this draw (the kernels are deterministic, so that does not vary between runs)
-        tol = TOL if (mode == "f32" or name.startswith("decoder.out.")) else KINK_TOL
-        assert rel <= tol, f"{kind}/{mode}: gradient of {name} is off by {rel:.2e} (L2-relative, bound {tol:.0e})"
+        tol = TOL if (not flips or name.startswith("decoder.out.")) else KINK_TOL
+        assert rel <= tol, (f"{kind}/{mode}: gradient of {name} is off by {rel:.2e} (L2-relative, bound {tol:.0e}, "
+                            f"{len(flips)} flipped ReLU units)")
+    assert not flips, (f"{kind}/{mode}: gradients are within the fallback bound, but {len(flips)} ReLU unit(s) changed "
+                       f"sides ({flips[:8]}): pick another draw (SEED) so that the strict bound is the one tested")
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
