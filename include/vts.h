@@ -100,6 +100,12 @@ int vts_lstm_inproj_fwd(const float* x, const float* w_ih, const float* b_ih, co
 int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_last, float* c_last,
                            const float* w_hh, void* workspace, size_t workspace_bytes, int64_t B,
                            int64_t T, int64_t H, int dtype_mode, vts_stream_t stream);
+/* Status of the last vts_lstm_recurrent_fwd / _fwd_planes / vts_lstm_layer_fwd launch that used `workspace`, copied
+ * (device to device, on `stream`, behind that launch) into the device word *status: 0 = completed; 1 = the
+ * bench-sized forward kernel, whose workgroups hand h_t to each other, gave up waiting for a peer: its h sequence
+ * and final states then hold NaN.  (No counterpart in the reference: torch raises on the host.) */
+int vts_lstm_recurrent_fwd_status(const void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H,
+                                  int32_t* status, vts_stream_t stream);
 /* reverse recurrence: gates (activations in, pre-activation gradients out), bias gradients */
 int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq_t16,
                            const float* dh_last, const float* dc_last, const float* w_hh,
@@ -166,6 +172,10 @@ int vts_lstm_dgrad_planes(const void* dg_planes, const float* w_ih, float* dx_t1
 int vts_lstm_wgrad_planes(const void* dg_planes, const void* x_planes, int x_is_hseq, const void* h_planes, float* dw_ih,
                           float* dw_hh, int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
                           int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream);
+
+/* Test hook, process-wide: member `member` (0..7) of every cluster of the bench-sized forward recurrence withholds
+ * its hand-off flags and the waits are cut short, so the timeout path above can be exercised; -1 = off (default). */
+void vts_debug_set_cluster_fault(int member);
 
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,

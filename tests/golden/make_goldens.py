@@ -145,13 +145,15 @@ def single_case(root, kind, shape_name, threshold, seed, tweak=None, train=True,
     print(f"{name}: loss={float(loss):.9g}  params={sum(v.numel() for v in sd0.values())}")
 
 
-def adam_trajectory(root, kind, lr, steps=5, seed=7):
+def adam_trajectory(root, kind, lr, steps=5, seed=7, tweak=None, tag=None):
     """k optimiser steps at the reference-native shape (train-loop body:
     gaussian-lstm-DE.py:149-156, gpd-lstm-DE.py:99-105, mixture-vae-DE.py:158-164)."""
     B, T, C, H, L = SHAPES["native"]
     ns = load_reference(root, kind, 95.0)
     torch.manual_seed(seed)
     model = ns["VAE"](input_dim=C, lstm_output_dim=H, latent_dim=L, future_steps=1)
+    if tweak is not None:
+        tweak(model)
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     blob = {"meta/dims": np.array([B, T, C, H, L, 1], dtype=np.int64),
             "meta/threshold": np.float64(95.0), "meta/beta": np.float64(model.beta),
@@ -168,8 +170,9 @@ def adam_trajectory(root, kind, lr, steps=5, seed=7):
         blob.update(pack(f"step{s}/noise", noise))
     blob["losses"] = np.array(losses, dtype=np.float32)
     blob.update(pack("sdK", model.state_dict()))
-    np.savez(os.path.join(HERE, f"adam_{kind}_native.npz"), **blob)
-    print(f"adam_{kind}_native: losses={losses}")
+    name = tag or f"adam_{kind}_native"
+    np.savez(os.path.join(HERE, name + ".npz"), **blob)
+    print(f"{name}: losses={losses}")
 
 
 def main():
@@ -178,6 +181,13 @@ def main():
         return
     root = sys.argv[1]
     torch.set_num_threads(1)
+    if len(sys.argv) > 2 and sys.argv[2] == "--only-wellcond-trajectory":   # adds that one fixture, leaves the rest
+        def well_conditioned(model):
+            with torch.no_grad():
+                model.encoder.shape_layer_extreme.weight.mul_(0.25)
+                model.encoder.shape_layer_extreme.bias.fill_(0.5)
+        adam_trajectory(root, "gpd", 1e-3, tweak=well_conditioned, tag="adam_gpd_native_wellcond")
+        return
     for kind in SCRIPTS:
         for si, shape_name in enumerate(SHAPES):
             single_case(root, kind, shape_name, 95.0, seed=11 + 3 * si)
@@ -209,6 +219,9 @@ def main():
     adam_trajectory(root, "gaussian", 5e-3)
     adam_trajectory(root, "gpd", 1e-3)
     adam_trajectory(root, "mixture", 1e-3)
+    # the GPD train loop (gpd-lstm-DE.py:99-105) from a state whose sampler is well conditioned: a trajectory
+    # that can be held to the same bounds as the other two models
+    adam_trajectory(root, "gpd", 1e-3, tweak=well_conditioned, tag="adam_gpd_native_wellcond")
 
 
 if __name__ == "__main__":

@@ -403,13 +403,16 @@ def test_gpd_sampler_is_bit_exact_at_the_clamp():
 
 
 # --------------------------------------------------------------------------- Adam, a10
-@pytest.mark.parametrize("kind", ["gaussian", "mixture", "gpd"])
+@pytest.mark.parametrize("kind", ["gaussian", "mixture", "gpd", "gpd_wellcond"])
 def test_adam_trajectory(golden, kind):
+    """Five steps of the reference's train loop (gaussian-lstm-DE.py:149-156, gpd-lstm-DE.py:99-105,
+    mixture-vae-DE.py:158-164) replayed with its recorded inputs and draws.  gpd_wellcond: the GPD loop from a state
+    whose sampler is well conditioned (shape head biased to 0.5), held to the bounds of the other two models."""
     import vts
     dev = _dev()
-    g = golden(f"adam_{kind}_native")
+    g = golden(f"adam_{kind}_native" if kind != "gpd_wellcond" else "adam_gpd_native_wellcond")
     dims = [int(v) for v in g["meta"]["dims"]]
-    m = make_model(kind, dims, g["sd0"], g["meta"]["threshold"], g["meta"]["beta"], dev)
+    m = make_model(kind.split("_")[0], dims, g["sd0"], g["meta"]["threshold"], g["meta"]["beta"], dev)
     m.train()
     flat = vts.FlatParameters(m)
     opt = vts.Adam(flat, lr=g["meta"]["lr"])
@@ -460,11 +463,13 @@ def test_large_batch_against_oracle_slice(mode):
                 assert l2_rel(p.grad, grads_r[k]) < TOL, (kind, k, l2_rel(p.grad, grads_r[k]))
 
 
-def test_cluster_recurrence_timeout_is_loud(monkeypatch):
+def test_cluster_recurrence_timeout_is_loud():
     """The bench-sized forward recurrence runs as clusters of eight workgroups that wait for each other with
-    bounded polls.  With one member withholding its flags (fault injection through the environment, read at every
-    call) the launch must end, and h_n must come back NaN rather than as plausible numbers."""
+    bounded polls.  With one member withholding its flags (the library's test hook) the launch must end, h_n must
+    come back NaN rather than as plausible numbers, and the launch's status word must say so."""
     import vts
+    from vts import _lib as L
+    lib = L.load()
     dev = _dev()
     vts.set_mode("bf16x3")
     try:
@@ -475,13 +480,36 @@ def test_cluster_recurrence_timeout_is_loud(monkeypatch):
             _, (h_ok, _) = m(x)
             torch.cuda.synchronize()
             assert torch.isfinite(h_ok).all()
-            monkeypatch.setenv("VTS_LSTM_CLUSTER_FAULT", "3")
-            _, (h_bad, _) = m(x)
-            torch.cuda.synchronize()
-            monkeypatch.delenv("VTS_LSTM_CLUSTER_FAULT")
+            lib.vts_debug_set_cluster_fault(3)
+            try:
+                _, (h_bad, _) = m(x)
+                torch.cuda.synchronize()
+            finally:
+                lib.vts_debug_set_cluster_fault(-1)
             _, (h_again, _) = m(x)
             torch.cuda.synchronize()
         assert torch.isnan(h_bad).all(), "a missed hand-off must poison the layer's output"
         assert torch.equal(h_again, h_ok), "the next launch starts from cleared flags"
+
+        # the same through the C ABI, with the status word read back
+        B, T, H = 128, 6, 256
+        gates = torch.randn(B * T * 4 * H, device=dev) * 0.1
+        cells = torch.empty(B * T * H, device=dev)
+        hseq = torch.empty(B, T, H, device=dev)
+        w_hh = torch.randn(4 * H, H, device=dev) * 0.05
+        ws_bytes = lib.vts_lstm_recurrent_workspace_bytes(B, T, H)
+        ws = L.workspace(ws_bytes, dev)
+        status = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        for fault, want in ((-1, 0), (5, 1), (-1, 0)):
+            lib.vts_debug_set_cluster_fault(fault)
+            try:
+                L.check(lib.vts_lstm_recurrent_fwd(L.wptr(gates.clone()), L.ptr(cells), L.ptr(hseq), None, None, L.ptr(w_hh),
+                                                   L.wptr(ws), ws_bytes, B, T, H, 1, L.stream()), "vts_lstm_recurrent_fwd")
+            finally:
+                lib.vts_debug_set_cluster_fault(-1)
+            L.check(lib.vts_lstm_recurrent_fwd_status(L.wptr(ws), ws_bytes, B, T, H, L.wptr(status), L.stream()),
+                    "vts_lstm_recurrent_fwd_status")
+            torch.cuda.synchronize()
+            assert status.item() == want, (fault, status.item())
     finally:
         vts.set_mode("f32")

@@ -35,7 +35,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 B, T, C, H, LD = 4096, 96, 370, 256, 32
 THRESHOLD = 0.8          # |y| <= 0.8: a mixed normal / extreme mask on N(0, 1) targets
-SEED = {"mixture": 11, "gpd": 11, "gaussian": 11}     # draws in which no ReLU unit changes sides (checked below)
+SEED = {"mixture": 11, "gpd": 11, "gaussian": 12}     # draws in which no ReLU unit changes sides (checked below)
 KINK_TOL = 2e-3         # fallback bound when one does: see the module docstring
 RELU_SITES = {"gaussian": [("decoder.dense1", None)],
               "gpd": [("encoder.fc1", None), ("encoder.fc2", "enc_keep"), ("decoder.fc1", None), ("decoder.fc2", "dec_keep")]}

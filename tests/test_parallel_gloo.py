@@ -60,11 +60,17 @@ def _worker(rank, world, port, x, y, ref_grad, ret):
     parallel.plan_buckets = lambda flat, max_buckets=3, min_floats=1 << 18: orig(flat, 3, 1000)
     trainer = vts.DataParallelTrainer(model, optimizer_factory=NoOpt)
     assert len(trainer.buckets) == 3
+    trainer.trace = True
     xs, ys = vts.shard_batch(x, rank, world), vts.shard_batch(y, rank, world)
     loss = trainer.step(xs, ys)
     gl = trainer.global_loss(loss)
     got = trainer.flat.grad / world
-    ret[rank] = (float((got - ref_grad).abs().max()), float(gl), trainer.opt.scale)
+    # overlap: the first bucket's all-reduce is issued while later parameters are still waiting for their gradients
+    ev = trainer.events
+    first_reduce = next(i for i, e in enumerate(ev) if e[0] == "allreduce")
+    last_grad = max(i for i, e in enumerate(ev) if e[0] == "grad")
+    n_reduce = sum(1 for e in ev if e[0] == "allreduce")
+    ret[rank] = (float((got - ref_grad).abs().max()), float(gl), trainer.opt.scale, first_reduce < last_grad, n_reduce)
     dist.destroy_process_group()
 
 
@@ -88,7 +94,9 @@ def test_two_rank_gradient_equals_full_batch_gradient():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), x, y, ref_grad, ret), nprocs=world, join=True)
     for rank in range(world):
-        err, gl, scale = ret[rank]
+        err, gl, scale, overlapped, n_reduce = ret[rank]
         assert err < 1e-6, err
         assert abs(gl - loss.item()) < 1e-6
         assert scale == 0.5
+        assert overlapped, "no all-reduce was issued before the last gradient was final"
+        assert n_reduce == 3

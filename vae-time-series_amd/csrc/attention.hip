@@ -296,7 +296,7 @@ int launch_mha(const MhaParams& P, bool bwd, hipStream_t st) {
   }
   const unsigned grid = (unsigned)(((long)P.B * P.nhead + 3) / 4);
   // the LDS request varies with T, so the opt-in above 64 KiB is renewed per launch rather than cached
-  unsigned long long fresh = 0;
+  vts_lds_mask fresh{0};
   if (bwd) {
     if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mha_bwd_kernel<DH>), bytes, &fresh, "mha_bwd")) return rc;
     hipLaunchKernelGGL(mha_bwd_kernel<DH>, dim3(grid), dim3(256), bytes, st, P);

@@ -317,7 +317,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 
 template <bool BWD, int DROP, bool BITS>
 int launch_b2b(const FfnParams& P, hipStream_t st) {
-  static unsigned long long done = 0;
+  static vts_lds_mask done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_b2b_kernel<BWD, DROP, BITS>), LDS_BYTES, &done, "ffn_b2b"))
     return rc;
   hipLaunchKernelGGL((ffn_b2b_kernel<BWD, DROP, BITS>), dim3((unsigned)((P.M + TOK - 1) / TOK)), dim3(512), LDS_BYTES, st, P);

@@ -1126,7 +1126,7 @@ template <int AK, int BKIND, int CK, bool PLAIN>
 int launch3big(const GemmParams& P, hipStream_t stream) {
   const int tiles_m = vts_cdiv(P.M, BMB), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
-  static unsigned long long lds_done = 0;   // per instantiation
+  static vts_lds_mask lds_done{0};   // per instantiation
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_bf16x3_big_kernel<AK, BKIND, CK, PLAIN>),
                                GEMM3B_LDS_BYTES, &lds_done, "gemm_bf16x3_big"))
     return rc;
@@ -1141,7 +1141,7 @@ int launch3p(const GemmParams& P, hipStream_t stream) {
   if (use_big_tile(P)) return launch3big<AK, BKIND, CK, PLAIN>(P, stream);
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
-  static unsigned long long lds_done = 0;   // per instantiation
+  static vts_lds_mask lds_done{0};   // per instantiation
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_bf16x3_kernel<AK, BKIND, CK, PLAIN>), GEMM3_LDS_BYTES,
                                &lds_done, "gemm_bf16x3"))
     return rc;
@@ -1155,7 +1155,7 @@ int launchp(const GemmParams& P, hipStream_t stream) {
   const int tiles_m = vts_cdiv(P.M, BM), tiles_n = vts_cdiv(P.N, BN);
   const long nwg = (P.ksplit > 1) ? 8L * vts_cdiv(P.ksplit, 8) * tiles_m * tiles_n : 8L * vts_cdiv(tiles_m, 8) * tiles_n;
   dim3 grid((unsigned)nwg, 1, 1);
-  static unsigned long long lds_done = 0;   // per instantiation
+  static vts_lds_mask lds_done{0};   // per instantiation
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(gemm_f32_kernel<AK, BKIND, CK, PLAIN>), GEMM_LDS_BYTES,
                                &lds_done, "gemm_f32"))
     return rc;

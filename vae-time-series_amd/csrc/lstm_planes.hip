@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-unsigned long long g_lds_row = 0, g_lds_wgrad = 0;
+vts_lds_mask g_lds_row{0}, g_lds_wgrad{0};
 
 int grid_cus() {
   int dev = 0, cus = 256;

@@ -543,7 +543,7 @@ int run_fwd3(float* G, float* cseq, float* hseq, float* hlast, float* clast, con
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL((pack_whh3_kernel<H, false>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3_fwd");
-  static unsigned long long lds_done = 0;
+  static vts_lds_mask lds_done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_fwd_kernel<H, PL>), R::LDS_F, &lds_done, "lstm_rec3_fwd")) return rc;
   hipLaunchKernelGGL((lstm_rec3_fwd_kernel<H, PL>), dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_F, stream, G, cseq, hseq,
                      hlast, clast, img, B, T, hp);
@@ -559,7 +559,7 @@ int run_bwd3(float* G, const float* cseq, const float* dhseq, const float* dhlas
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL((pack_whh3_kernel<H, true>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3_bwd");
-  static unsigned long long lds_done = 0;
+  static vts_lds_mask lds_done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_bwd_kernel<H, PL>), R::LDS_B, &lds_done, "lstm_rec3_bwd")) return rc;
   hipLaunchKernelGGL((lstm_rec3_bwd_kernel<H, PL>), dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_B, stream, G, cseq, dhseq,
                      dhlast, dclast, dbpart, img, B, T, dgp);

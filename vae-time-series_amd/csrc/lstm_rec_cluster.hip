@@ -18,6 +18,7 @@
 #include "lstm_rec_common.h"
 #include "gemm_planes.h"
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 }  // namespace
 
 // The cluster kernel serves the bench-sized launches: hidden 256, whole clusters, and a grid that is resident
-// at once at one workgroup per CU (its members wait for each other).
+// at once at one workgroup per CU (its members wait for each other).  This is the cheap shape test; whether the
+// grid really is co-resident is the launch's business (cooperative launch below).
 bool vts_lstm_rec3c_usable(int B, int T, int H) {
   if (H != CH || B < CROWS || (B % CROWS) != 0 || T < 2) return false;
   int dev = 0, cus = 0;
@@ -400,35 +402,68 @@ bool vts_lstm_rec3c_usable(int B, int T, int H) {
   return 64 * vts_cdiv(nclusters, 8) <= cus;
 }
 
-// xws: exchange buffers (X_CLUSTER bytes per cluster) followed by the flags; fws: flag words + error word.
+// Test hook: member `member` (0..7) of every cluster withholds its flags and the polls give up after 1024 rounds, so
+// that the timeout path can be exercised; -1 (the default) = off.  Process-wide, not for production callers.
+static std::atomic<int> g_fault_member{-1};
+extern "C" void vts_debug_set_cluster_fault(int member) { g_fault_member.store(member < 0 ? -1 : (member & (NC - 1))); }
+
+// xws: exchange buffers (X_CLUSTER bytes per cluster) followed by the flags; fws: flag words; err: the launch's
+// status word (cleared by the caller).
 size_t vts_lstm_rec3c_xchg_bytes(int B) { return (size_t)(B / CROWS) * X_CLUSTER; }
 size_t vts_lstm_rec3c_flag_bytes(int B) { return ((size_t)(B / CROWS) * NC + 1) * FLAG_STRIDE * sizeof(unsigned); }
 
+// Returns VTS_OK, an error, or VTS_ERR_UNSUPPORTED with nothing launched when the runtime will not guarantee that
+// the whole grid is resident at once (another tenant on the device, a CU mask, too few CUs): the caller then takes
+// the one-workgroup kernel.  The launch is a cooperative one for exactly that guarantee: the members of a cluster
+// wait for each other, so a grid that is only partly resident would spin until the polls time out.
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
-                       void* xws, void* fws, int B, int T, void* h_planes, hipStream_t stream) {
+                       void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream) {
   const int nclusters = B / CROWS;
+  static vts_lds_mask lds_done{0};
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), C_LDS, &lds_done, "lstm_rec3c_fwd"))
+    return rc;
+  static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return !(e && e[0] == '0'); }();
+  const unsigned grid = 64 * vts_cdiv(nclusters, 8);
+  if (coop) {
+    // what the runtime would refuse at launch, asked beforehand so that nothing has been enqueued on a refusal
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), 256,
+                                                     C_LDS) != hipSuccess ||
+        (long)per_cu * cus < (long)grid) {
+      (void)hipGetLastError();
+      vts_set_error("lstm_rec3c_fwd: %u workgroups cannot be resident at once (%d per CU x %d CUs)", grid, per_cu, cus);
+      return VTS_ERR_UNSUPPORTED;
+    }
+  }
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL(pack_whh3c_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3c");
   unsigned* flags = reinterpret_cast<unsigned*>(fws);
-  unsigned* err = flags + (size_t)nclusters * NC * FLAG_STRIDE;
   if (hipMemsetAsync(flags, 0, vts_lstm_rec3c_flag_bytes(B), stream) != hipSuccess) {
     vts_set_error("lstm_rec3c_fwd: clearing the hand-off flags failed");
     return VTS_ERR_HIP;
   }
-  static unsigned long long lds_done = 0;
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), C_LDS, &lds_done, "lstm_rec3c_fwd"))
-    return rc;
-  // polls give up after about two seconds; VTS_LSTM_CLUSTER_FAULT=<member> (read at every call, tests only) makes
-  // that member withhold its flags and shortens the wait, to exercise the timeout path
-  int spin_limit = 1 << 21, mute_member = -1;
-  if (const char* e = getenv("VTS_LSTM_CLUSTER_FAULT")) {
-    mute_member = atoi(e) & (NC - 1);
-    spin_limit = 1 << 10;
+  // polls give up after about two seconds (1024 rounds under the test hook above)
+  int mute_member = g_fault_member.load();
+  int spin_limit = mute_member >= 0 ? 1 << 10 : 1 << 21;
+  unsigned long long* xchg = reinterpret_cast<unsigned long long*>(xws);
+  int nc = nclusters;
+  gp::SeqPlanes hp{reinterpret_cast<char*>(h_planes), 8, T + 1, 1};
+  if (coop) {
+    void* args[] = {&G, &cseq, &hseq, &hlast, &clast, &img, &xchg, &flags, &err, &T, &nc, &spin_limit, &mute_member, &hp};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), dim3(grid),
+                                                    dim3(256), args, C_LDS, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      vts_set_error("lstm_rec3c_fwd: cooperative launch refused: %s", hipGetErrorString(e));
+      return e == hipErrorCooperativeLaunchTooLarge ? VTS_ERR_UNSUPPORTED : VTS_ERR_HIP;
+    }
+    return VTS_OK;
   }
-  hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(64 * vts_cdiv(nclusters, 8)), dim3(256), C_LDS, stream, G, cseq, hseq,
-                     hlast, clast, img, reinterpret_cast<unsigned long long*>(xws), flags, err, T, nclusters, spin_limit,
-                     mute_member, gp::SeqPlanes{reinterpret_cast<char*>(h_planes), 8, T + 1, 1});
+  hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(grid), dim3(256), C_LDS, stream, G, cseq, hseq, hlast, clast, img, xchg,
+                     flags, err, T, nclusters, spin_limit, mute_member, hp);
   VTS_CHECK_LAUNCH("lstm_rec3c_fwd");
   return VTS_OK;
 }

@@ -460,7 +460,7 @@ int run_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, cons
   VTS_CHECK_LAUNCH("pack_whh_fwd");
   const int nbt = (B + 15) / 16;
   const size_t lds = (2ul * 16 * H + (size_t)(C::KQ_F / 8) * C::JPW * 4 * C::NW * 64 * 4) * sizeof(float);
-  static unsigned long long lds_done = 0;
+  static vts_lds_mask lds_done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec_fwd_kernel<H>), lds, &lds_done, "lstm_rec_fwd"))
     return rc;
   hipLaunchKernelGGL(lstm_rec_fwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), lds, stream, G, cseq, hseq, hlast, clast,
@@ -477,7 +477,7 @@ int run_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast
   VTS_CHECK_LAUNCH("pack_whh_bwd");
   const int nbt = (B + 15) / 16;
   const size_t lds = 2ul * 16 * C::LDA * sizeof(float);
-  static unsigned long long lds_done = 0;
+  static vts_lds_mask lds_done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec_bwd_kernel<H>), lds, &lds_done, "lstm_rec_bwd"))
     return rc;
   hipLaunchKernelGGL(lstm_rec_bwd_kernel<H>, dim3(nbt), dim3(C::NW * 64), lds, stream, G, cseq, dhseq, dhlast,

@@ -68,7 +68,7 @@ int vts_planes_dgrad(const void* dg_planes, const float* w_ih, float* dx_t16, vo
 int vts_planes_wgrad(const void* dg_planes, const void* s_planes, int x_zero_slot, const void* h_planes, float* dw_ih,
                      float* dw_hh, int accumulate, float* slabs, long B, long T, long F, long H, hipStream_t st);
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
-                       void* xws, void* fws, int B, int T, void* h_planes, hipStream_t stream);
+                       void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream);
 int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
                       float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, void* dg_planes,
                       hipStream_t stream);
@@ -178,9 +178,14 @@ static size_t rec_ws_dbpart_bytes(int64_t B, int64_t H) {
 }
 static size_t rec_ws_seed_bytes(int64_t B, int64_t H) { return round256((size_t)pad16(B) * H * sizeof(float)); }
 // [packed W_hh image][bias-gradient partials][dh_T in tile16 order][dc_T in tile16 order]
+// ... [status word of the forward launch, 256 B]
 size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
   (void)T;
-  return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H);
+  return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H) + 256;
+}
+static unsigned* rec_ws_status(void* workspace, int64_t B, int64_t H) {
+  return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) +
+                                     2 * rec_ws_seed_bytes(B, H));
 }
 size_t vts_lstm_wgrad_workspace_bytes(int64_t B, int64_t T, int64_t F, int64_t H) {
   const int M = (int)(4 * H);
@@ -243,12 +248,20 @@ static int recurrent_fwd_impl(float* gates, float* cells, float* hseq, float* h_
   // live in the parts of the workspace that only the backward pass uses (gradient seeds, bias partials), which
   // are exactly large enough: 2 KiB and 256 B per window against 2 KiB and ~8 B needed.
   static const bool cluster_on = [] { const char* e = getenv("VTS_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
+  // status word of this launch (vts_lstm_recurrent_fwd_status): only the cluster kernel can set it
+  unsigned* status = rec_ws_status(workspace, B, H);
+  if (hipMemsetAsync(status, 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+    vts_set_error("lstm_recurrent_fwd: clearing the status word failed");
+    return VTS_ERR_HIP;
+  }
   if (dtype_mode == 1 && cluster_on && vts_lstm_rec3c_usable((int)B, (int)T, (int)H)) {
     char* ws = reinterpret_cast<char*>(workspace);
     char* fws = ws + rec_ws_pack_bytes(H);
     char* xws = fws + rec_ws_dbpart_bytes(B, H);
-    return vts_lstm_rec3c_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), xws, fws,
-                              (int)B, (int)T, h_planes, reinterpret_cast<hipStream_t>(stream));
+    const int rc = vts_lstm_rec3c_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), xws, fws,
+                                      status, (int)B, (int)T, h_planes, reinterpret_cast<hipStream_t>(stream));
+    // the runtime would not guarantee a resident grid: nothing was launched, take the one-workgroup kernel
+    if (rc != VTS_ERR_UNSUPPORTED) return rc;
   }
   // bf16x3 recurrence for the hidden sizes it is built for; smaller ones stay on the fp32 kernel
   if (dtype_mode == 1 && vts_lstm_rec3_supported((int)H))
@@ -257,6 +270,20 @@ static int recurrent_fwd_impl(float* gates, float* cells, float* hseq, float* h_
   VTS_REQUIRE(!h_planes, "lstm_recurrent_fwd: plane output needs dtype_mode 1");
   return vts_lstm_rec_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), (int)B,
                           (int)T, (int)H, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_lstm_recurrent_fwd_status(const void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H,
+                                  int32_t* status, vts_stream_t stream) {
+  VTS_RC(lstm_check(B, T, 1, H));
+  VTS_REQUIRE(workspace && status, "lstm_recurrent_fwd_status: null pointer");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_recurrent_workspace_bytes(B, T, H),
+              "lstm_recurrent_fwd_status: workspace %zu B too small", workspace_bytes);
+  if (hipMemcpyAsync(status, rec_ws_status(const_cast<void*>(workspace), B, H), sizeof(int32_t), hipMemcpyDeviceToDevice,
+                     reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+    vts_set_error("lstm_recurrent_fwd_status: copy failed");
+    return VTS_ERR_HIP;
+  }
+  return VTS_OK;
 }
 
 int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_last, float* c_last, const float* w_hh,

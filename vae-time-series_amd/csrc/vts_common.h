@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #define VTS_OK 0
 #define VTS_ERR_ARG 1      // bad shape / pointer / alignment
@@ -33,20 +34,22 @@ void vts_set_error(const char* fmt, ...);
   } while (0)
 
 // Kernels that use more than 64 KiB of dynamic LDS must opt in with hipFuncSetAttribute, which
-// applies to the current device only: `done` (one static word per call site) remembers which
-// devices of this process have been configured.  Setting it twice is harmless, so no locking.
-static inline int vts_reserve_lds(const void* kernel, size_t bytes, unsigned long long* done, const char* what) {
+// applies to the current device only: `done` (one static atomic word per call site) remembers which
+// devices of this process have been configured.  Calls come from any host thread (autograd runs
+// backward on its own), hence the atomic; setting the attribute twice is harmless, so no lock.
+typedef std::atomic<unsigned long long> vts_lds_mask;
+static inline int vts_reserve_lds(const void* kernel, size_t bytes, vts_lds_mask* done, const char* what) {
   if (bytes <= 64 * 1024) return VTS_OK;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   const unsigned long long bit = 1ull << (dev & 63);
-  if (*done & bit) return VTS_OK;
+  if (done->load(std::memory_order_acquire) & bit) return VTS_OK;
   hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) {
     vts_set_error("%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
     return VTS_ERR_HIP;
   }
-  *done |= bit;
+  done->fetch_or(bit, std::memory_order_release);
   return VTS_OK;
 }
 

@@ -68,6 +68,10 @@ class DataParallelTrainer:
         self.buckets = plan_buckets(self.flat, max_buckets)
         self._pending: List = []
         self._remaining: List[int] = []
+        # trace = True records the order of events of a step: ("grad", parameter index) when a parameter's gradient is
+        # final, ("allreduce", bucket index) when a bucket's collective is issued (tests of the overlap)
+        self.trace = False
+        self.events: List[Tuple[str, int]] = []
         self._bucket_of: Dict[int, int] = {}
         for pi, (p, off) in enumerate(zip(self.flat.params, self.flat.offsets)):
             for bi, (s, e) in enumerate(self.buckets):
@@ -82,8 +86,12 @@ class DataParallelTrainer:
         def hook(_param):
             bi = self._bucket_of[pi]
             self._remaining[bi] -= 1
+            if self.trace:
+                self.events.append(("grad", pi))
             if self._remaining[bi] == 0:
                 s, e = self.buckets[bi]
+                if self.trace:
+                    self.events.append(("allreduce", bi))
                 self._pending.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM,
                                                      group=self.group, async_op=True))
         return hook
@@ -92,6 +100,7 @@ class DataParallelTrainer:
         self.opt.zero_grad()
         self._remaining = list(self._counts)
         self._pending = []
+        self.events = []
         if self.exact_loss:
             from . import functional as F
             F.set_loss_reduction(lambda sums: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group), self.world)
@@ -107,6 +116,8 @@ class DataParallelTrainer:
             for bi, left in enumerate(self._remaining):
                 if left > 0:
                     s, e = self.buckets[bi]
+                    if self.trace:
+                        self.events.append(("allreduce", bi))
                     self._pending.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
             for work in self._pending:
