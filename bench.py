@@ -51,10 +51,15 @@ def parse():
     ap.add_argument("--d-model", type=int, default=64)
     ap.add_argument("--nhead", type=int, default=8)
     ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--shape", default="ld2011", choices=["ld2011", "hurricane"],
+                    help="ld2011: 96-step x 370-channel standardised-load windows, hidden 256 (the headline workload); "
+                         "hurricane: the reference's own window shape (gpd-lstm-DE.py:77-84: 16 steps x 1 channel, hidden "
+                         "64, latent 32) filled with an AR(1) intensity walk and block-maximum targets; use with "
+                         "--model gpd --batch 16|4096|65536")
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU")
-    ap.add_argument("--T", type=int, default=96)
-    ap.add_argument("--C", type=int, default=370)
-    ap.add_argument("--H", type=int, default=256)
+    ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--C", type=int, default=None)
+    ap.add_argument("--H", type=int, default=None)
     ap.add_argument("--L", type=int, default=32)
     ap.add_argument("--mode", default="bf16x3", choices=["f32", "bf16x3"],
                     help="arithmetic of the LSTM's dense products: fp32 operands on the f32 matrix cores, or each "
@@ -68,7 +73,10 @@ def parse():
                     help="also measure roofline.traffic: two short child runs of this script under rocprofv3 --pmc "
                          "(FETCH_SIZE, WRITE_SIZE), started before this process touches the GPU; adds about a minute")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    a = ap.parse_args()
+    dT, dC, dH = (16, 1, 64) if a.shape == "hurricane" else (96, 370, 256)
+    a.T, a.C, a.H = a.T or dT, a.C or dC, a.H or dH
+    return a
 
 
 def synth_windows(B, T, C, rank, device):
@@ -79,6 +87,21 @@ def synth_windows(B, T, C, rank, device):
     x[zeros] = 0.0
     y = torch.randn(B, 1, generator=g)
     return x.to(device), y.to(device)
+
+
+def synth_hurricane(B, rank, device, T=16, horizon=8):
+    """Hurricane-intensity-shaped windows of the reference's block-maximum task (vae-models/graph/
+    training_block_max_hurdat.py:81-106 builds them from HURDAT2; here synthetic): per window an AR(1) walk
+    x_t = 0.9 x_{t-1} + 0.3 N(0,1) from x_0 ~ N(0.18, 0.89^2), clipped to the range of the standardised training
+    inputs [-1.66, 3.57]; X = the first T steps [B, T, 1], y = the maximum of the next `horizon` steps [B, 1]."""
+    g = torch.Generator().manual_seed(4321 + rank)
+    x = torch.empty(B, T + horizon)
+    x[:, 0] = 0.18 + 0.89 * torch.randn(B, generator=g)
+    steps = 0.3 * torch.randn(B, T + horizon, generator=g)
+    for t in range(1, T + horizon):
+        x[:, t] = 0.9 * x[:, t - 1] + steps[:, t]
+    x.clamp_(-1.66, 3.57)
+    return x[:, :T, None].contiguous().to(device), x[:, T:].max(dim=1, keepdim=True).values.to(device)
 
 
 def lstm_flops(kind, B, T, C, H):
@@ -489,7 +512,7 @@ def measure_traffic(a):
         return {"error": "rocprofv3 not on PATH"}
     top = tempfile.mkdtemp(prefix="vts_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--steps", "2", "--warmup", "1",
-             "--no-cpu-baseline", "--model", a.model, "--batch", str(a.batch), "--T", str(a.T), "--C", str(a.C),
+             "--no-cpu-baseline", "--model", a.model, "--shape", a.shape, "--batch", str(a.batch), "--T", str(a.T), "--C", str(a.C),
              "--H", str(a.H), "--L", str(a.L), "--mode", a.mode]
     sums = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -501,8 +524,8 @@ def measure_traffic(a):
         except subprocess.TimeoutExpired:
             return {"error": f"rocprofv3 --pmc {counter} timed out"}
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        if rc != 0 or not files:
-            return {"error": f"rocprofv3 --pmc {counter} failed (exit {rc})"}
+        if not files:      # (the profiled interpreter may crash while exiting, after the counters are on disk)
+            return {"error": f"rocprofv3 --pmc {counter} left no counter file (exit {rc})"}
         per = {}
         for row in csv.DictReader(open(files[0])):
             if row.get("Counter_Name") != counter:
@@ -563,7 +586,12 @@ def main():
         model.threshold = 0.8
     trainer = vts.DataParallelTrainer(model, lr=1e-3, exact_loss=a.exact_loss)
     torch.manual_seed(4321 + rank)              # rank-offset noise streams
-    x, y = synth_windows(a.batch, a.T, a.C, rank, dev)
+    if a.shape == "hurricane":
+        if a.C != 1:
+            raise SystemExit("--shape hurricane is a single-channel series (C = 1)")
+        x, y = synth_hurricane(a.batch, rank, dev, a.T)
+    else:
+        x, y = synth_windows(a.batch, a.T, a.C, rank, dev)
     if a.model == "mixture3":
         y[::16] = 0.0
 
@@ -680,7 +708,9 @@ def main():
             "dtype": "f32" if a.mode == "f32" else "bf16x3 (fp32 operands split into two bf16, three bf16 MFMA "
                                                     "products per fp32 product, fp32 accumulate); f32 elsewhere",
             "data": "synthetic",
-            "config": {"workload": f"{a.model} LSTM-VAE train step, LD2011-shaped windows: {a.batch} windows/GPU x "
+            "config": {"workload": f"{a.model} LSTM-VAE train step, "
+                                   f"{'LD2011-shaped' if a.shape == 'ld2011' else 'hurricane-shaped (AR(1) walk, block-maximum target)'} "
+                                   f"windows: {a.batch} windows/GPU x "
                                    f"{a.T} steps x {a.C} channels, hidden {a.H}, latent {a.L}, future_steps 1",
                        "model_kind": a.model, "windows_per_gpu": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "rccl_ranks": world if launched else 0, "gemm_mode": a.mode,

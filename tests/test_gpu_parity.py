@@ -463,6 +463,39 @@ def test_large_batch_against_oracle_slice(mode):
                 assert l2_rel(p.grad, grads_r[k]) < TOL, (kind, k, l2_rel(p.grad, grads_r[k]))
 
 
+@pytest.mark.parametrize("mode", MODES, indirect=True)
+@pytest.mark.parametrize("kind,thr", [("gpd", 95.0), ("mixture", 95.0), ("mixture", None)])
+def test_hurricane_shaped_windows_against_oracle(kind, thr, mode):
+    """The reference's own window shape at a bench-sized batch (gpd-lstm-DE.py:77-84: 16 steps x 1 channel, hidden
+    64, latent 32; 4096 windows) on the synthetic hurricane-shaped data bench.py --shape hurricane times: an AR(1)
+    intensity walk with block-maximum targets.  thr None = the 90th percentile of |y|: a mixed normal / extreme mask
+    (mixture-vae-DE.py:116-119)."""
+    import bench
+    dev = _dev()
+    B, T, C, H, Ld = 4096, 16, 1, 64, 32
+    x, y = bench.synth_hurricane(B, 0, torch.device("cpu"), T)
+    assert x.shape == (B, T, C) and y.shape == (B, 1)
+    assert x.min() >= -1.66 and x.max() <= 3.57 and (y >= x[:, -1] * 0.9 - 5).all()
+    if thr is None:
+        thr = float(y.abs().quantile(0.9))
+    sd = R.init_state(kind, C, H, Ld, 1, seed=4)
+    sd["encoder.shape_layer_extreme.weight"] *= 0.25      # GPD shapes off the 1e-6 clamp (ill-conditioned sampler)
+    sd["encoder.shape_layer_extreme.bias"].fill_(0.5)
+    noise = R.draw_noise(kind, B, Ld, seed=6)
+    loss_r, _, grads_r = R.loss_and_grads(kind, sd, x, y, noise, threshold=thr)
+    m = make_model(kind, (B, T, C, H, Ld, 1), sd, thr, 0.001, dev)
+    m.train()
+    outs = m(x.to(dev), {k: v.to(dev) for k, v in noise.items()})
+    loss = m.loss_function(outs[0], y.to(dev), *outs[1:])
+    loss.backward()
+    assert abs(loss.item() - loss_r.item()) <= TOL * abs(loss_r.item())
+    for k, p in m.named_parameters():
+        if k == "pi_params":
+            assert pi_grad_close(p.grad, grads_r[k], loss_r.item())
+        else:
+            assert l2_rel(p.grad, grads_r[k]) < TOL, (kind, k, l2_rel(p.grad, grads_r[k]))
+
+
 def test_cluster_recurrence_timeout_is_loud():
     """The bench-sized forward recurrence runs as clusters of eight workgroups that wait for each other with
     bounded polls.  With one member withholding its flags (the library's test hook) the launch must end, h_n must
