@@ -176,6 +176,11 @@ int vts_lstm_wgrad_planes(const void* dg_planes, const void* x_planes, int x_is_
 /* Test hook, process-wide: member `member` (0..7) of every cluster of the bench-sized forward recurrence withholds
  * its hand-off flags and the waits are cut short, so the timeout path above can be exercised; -1 = off (default). */
 void vts_debug_set_cluster_fault(int member);
+/* Development switch, process-wide: on != 0 lets vts_lstm_recurrent_bwd_planes run the bench-sized backward
+ * recurrence as clusters of eight workgroups with W_hh stationary (the forward pass always does); off (default,
+ * unless VTS_LSTM_CLUSTER_BWD=1 is set at start-up) it runs one workgroup per 16 windows, which measures 3 %
+ * faster.  Same results either way up to the order of fp32 sums. */
+void vts_debug_set_cluster_bwd(int on);
 
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,

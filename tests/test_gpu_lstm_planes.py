@@ -39,10 +39,22 @@ def _planes_taken(B, T, C, H):
     (384, 4, 64, 256, 2),     # 96 token tiles: output tiles spread unevenly over the workgroups
     (1024, 8, 256, 256, 3),   # 512 token tiles: more than one output tile per workgroup, 32 k-slices
 ])
-@pytest.mark.parametrize("need_output", [True, False])
-def test_plane_path_matches_torch_lstm(B, T, C, H, layers, need_output):
+@pytest.mark.parametrize("need_output,cluster_bwd", [(True, False), (False, False), (False, True)])
+def test_plane_path_matches_torch_lstm(B, T, C, H, layers, need_output, cluster_bwd):
+    """cluster_bwd: the backward recurrence as clusters of eight workgroups that exchange the gate gradients through
+    the plane buffer (off by default: vts_debug_set_cluster_bwd)."""
     import vts
+    from vts import _lib
     assert _planes_taken(B, T, C, H)
+    _lib.load().vts_debug_set_cluster_bwd(1 if cluster_bwd else 0)
+    try:
+        _run_plane_case(B, T, C, H, layers, need_output)
+    finally:
+        _lib.load().vts_debug_set_cluster_bwd(0)
+
+
+def _run_plane_case(B, T, C, H, layers, need_output):
+    import vts
     dev = _dev()
     g = torch.Generator().manual_seed(B * 1000 + T + C)
     lstm = vts.LSTM(C, H, num_layers=layers).to(dev)

@@ -49,7 +49,10 @@ def make_model(dims, sd, beta, dev):
 def run_vts(sd, dims, x, y, noise, threshold, beta, dev, train=True):
     m = make_model(dims, sd, beta, dev)
     m.train(train)
-    outs = m(x.to(dev), {k: v.to(dev) for k, v in noise.items()})
+    noise = dict(noise)
+    for i in range(dims[5]):    # fixtures recorded with attention dropout off carry no mask for it: say so explicitly
+        noise.setdefault(f"l{i}.attn_keep", False)
+    outs = m(x.to(dev), {k: (v if v is False else v.to(dev)) for k, v in noise.items()})
     loss = m.loss_function(outs[0], y.to(dev), *outs[1:], threshold)
     loss.backward()
     grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
@@ -316,6 +319,23 @@ def test_large_batch_bf16x3_matches_oracle():
         compare(loss, outs, grads, ref_loss.item(), ref_outs, ref_grads)
     finally:
         vts.set_mode("f32")
+
+
+def test_partial_noise_still_drops():
+    """A training call that feeds only the sampling draws must still apply dropout at every site."""
+    import vts
+    dev = _dev()
+    torch.manual_seed(0)
+    B, T, C, d, nhead, layers, L = 8, 6, 5, 64, 8, 2, 8
+    m = vts.TransformerMixtureVAE(C, d, layers, nhead, L, 1).to(dev)
+    x = torch.randn(B, T, C, device=dev)
+    part = {"eps": torch.randn(B, L, device=dev), "u": torch.rand(B, L, device=dev), "choice": torch.rand(B, device=dev)}
+    m.eval()
+    with torch.no_grad():
+        ref = m(x, part)[1]
+        m.train()
+        a, b = m(x, part)[1], m(x, part)[1]
+    assert not torch.equal(a, ref) and not torch.equal(a, b), "dropout was silently off (or repeated its mask)"
 
 
 def test_hashed_dropout_rate():

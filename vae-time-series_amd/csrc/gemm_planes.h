@@ -88,30 +88,42 @@ struct SeqPlanes {
 // slot h % 5), so the loads of k-step s+2 are issued during the products of k-step s: A_{s+2} takes the slot B_{s-1}
 // left at the end of the previous k-step, B_{s+2} takes A_s's slot once every wave holds its A fragments in
 // registers (the barrier after the fragment reads).  The DMA loads stay in flight across the barriers: waits are
-// counted (each wave issues eight per k-step, vmcnt(8) retires everything but the newest eight) and the barriers
+// counted (each wave issues NP = eight per k-step, vmcnt(NP) retires everything but the newest NP) and the barriers
 // are bare s_barrier instructions.  A slot is read only after a barrier that follows the wait that retired it.
-template <class Pol, bool TRANS, int DBG = 0>   // DBG (timing experiments only): 1 = no global loads, 2 = no products
+//
+// NTW = column tiles (of 16) per wave: 8 for the 256-column workgroup tile, 4 (transposed mode only) for a workgroup
+// tile of 256 x 128 - half the B tiles (li = (tt * 4 + cb) * 2 + p, 16 per k-step, two per wave), half the MFMAs:
+// for the last, half-filled column tile of a weight-gradient plan.  pol.flush then gets NTW accumulator columns.
+template <class Pol, bool TRANS, int NTW = 8, int DBG = 0>   // DBG (timing experiments only): 1 = no global loads, 2 = no products
 __device__ __forceinline__ void mainloop(Pol& pol, int nsteps, int nk, char* lds) {
-  f32x4 acc[4][8];
+  static_assert(NTW == 8 || (NTW == 4 && TRANS), "column tiles per wave");
+  constexpr int NP = 4 + NTW / 2;     // tile loads a wave issues per k-step
+  f32x4 acc[4][NTW];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (nsteps <= 0) return;
 
-  // piece q (0..7) of a wave's loads for k-step s: q < 4 -> A tile 4 * wave + q; q >= 4 -> B tile 4 * wave + q - 4
+  // piece q (0..NP-1) of a wave's loads for a k-step: q < 4 -> A tile 4 * wave + q; q >= 4 -> B tile
+  // (NTW / 2) * wave + q - 4
   auto issue_piece = [&](int slot_a, int slot_b, int q) {
-    const int li = 4 * wave + (q & 3);
-    if (q < 4) glds16(pol.a_tile(li) + lane * 16, lds + slot_a * HALF_B + li * TILE_B);
-    else       glds16(pol.b_tile(li) + lane * 16, lds + slot_b * HALF_B + li * TILE_B);
+    if (q < 4) {
+      const int li = 4 * wave + q;
+      glds16(pol.a_tile(li) + lane * 16, lds + slot_a * HALF_B + li * TILE_B);
+    } else {
+      const int li = (NTW / 2) * wave + (q - 4);
+      glds16(pol.b_tile(li) + lane * 16, lds + slot_b * HALF_B + li * TILE_B);
+    }
   };
   auto next2 = [](int sl) { return sl >= 3 ? sl - 3 : sl + 2; };   // (sl + 2) % 5
 
   // per-lane byte offsets of the fragment reads inside a half stage
   int off0, off1 = 0;   // direct: off0; transposed: off0 (h = 0) and off1 (h = 1)
+  int ttb = 0;          // transposed, NTW = 4: what the second row tile's B tiles sit closer than A's (8 tiles, not 16)
   if (!TRANS) {
     off0 = slot(lane >> 4, lane & 15) * 16;
   } else {
@@ -120,11 +132,12 @@ __device__ __forceinline__ void mainloop(Pol& pol, int nsteps, int nk, char* lds
     const int base = (gq >> 1) * (16 * TILE_B) + (p >> 1) * 256 + (p & 1) * 8;
     off0 = base + ((row0 ^ ((p >> 1) << 1)) << 4);
     off1 = base + (((row0 + 2) ^ ((p >> 1) << 1)) << 4);
+    if (NTW == 4) ttb = (gq >> 1) * (8 * TILE_B);
   }
   // fragment of 16-row (or, transposed, 16-column) block wbase + j of the workgroup's 256, plane p; j and p are
   // compile-time after unrolling (the transposed read takes them as an immediate offset), wbase is the wave's
   const int wa = TRANS ? wm * 4 * TILE_B : wm * 8 * TILE_B;      // byte offset of the wave's first A block
-  const int wb = TRANS ? wn * 8 * TILE_B : wn * 16 * TILE_B;     // and of its first B block
+  const int wb = (TRANS ? wn * NTW * TILE_B : wn * 16 * TILE_B) - ttb;     // and of its first B block
   auto frag = [&](const char* half, int woff, int j, int p) -> u32x4 {
     if (!TRANS) return *reinterpret_cast<const u32x4*>(half + woff + (j * 2 + p) * TILE_B + off0);
     const unsigned t = lds_addr(half) + woff;
@@ -136,12 +149,12 @@ __device__ __forceinline__ void mainloop(Pol& pol, int nsteps, int nk, char* lds
   if (DBG != 1) {
     pol.advance();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) issue_piece(0, 1, q);
+    for (int q = 0; q < NP; ++q) issue_piece(0, 1, q);
     if (nsteps > 1) {
       pol.advance();
 #pragma unroll
-      for (int q = 0; q < 8; ++q) issue_piece(2, 3, q);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      for (int q = 0; q < NP; ++q) issue_piece(2, 3, q);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -175,12 +188,15 @@ __device__ __forceinline__ void mainloop(Pol& pol, int nsteps, int nk, char* lds
     // B fragments one column tile ahead of their MFMAs; the scheduling fences keep the compiler from hoisting
     // all sixteen fragment reads to the top (128 registers) and spilling the accumulators.
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-      if (more) issue_piece(sa2, sb2, nt);
+    for (int nt = 0; nt < NTW; ++nt) {
+      if (more) {
+        issue_piece(sa2, sb2, nt);
+        if (nt + NTW < NP) issue_piece(sa2, sb2, nt + NTW);
+      }
       if (DBG != 2) {
         if (TRANS) wait_frag(bh, bl);
         u32x4 nh = bh, nl = bl;
-        if (nt < 7) {
+        if (nt < NTW - 1) {
           nh = frag(Bs, wb, nt + 1, 0);
           nl = frag(Bs, wb, nt + 1, 1);
         }
@@ -197,7 +213,7 @@ __device__ __forceinline__ void mainloop(Pol& pol, int nsteps, int nk, char* lds
         bh = nh; bl = nl;
       }
     }
-    if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // k-step s+1 has landed, s+2 stays in flight
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");    // k-step s+1 has landed, s+2 stays in flight
     else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -208,7 +224,7 @@ __device__ __forceinline__ void mainloop(Pol& pol, int nsteps, int nk, char* lds
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
 }

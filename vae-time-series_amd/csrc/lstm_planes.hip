@@ -153,94 +153,124 @@ __global__ __launch_bounds__(512) void rowgemm_planes_kernel(SeqPlanes A, const 
 
 // ---- weight gradients ---------------------------------------------------------------------------------------
 // slab[z][m'][n] = sum over the k-steps of slice z of dG[token][m'] * B[token][n], B = [layer input | h one step
-// back | zero padding].  Both operands are read with the transposed fragment read; a k-step is two token tiles.
+// back].  Both operands are read with the transposed fragment read; a k-step is two token tiles.  B's column
+// blocks (32 columns each) are cut into full column tiles of eight and, when four or fewer remain, one half tile
+// (NTW = 4: half the B loads and MFMAs per k-step, so its workgroups take longer k-slices).
+template <int NTW>
 struct WgradPol {
   SeqPlanes dG, X, Hs;          // Hs.t0 = 0: slot t holds h_{t-1}
   int T;
   int ncb_x, ncb_h;
   const char* zero;
-  float* slab; int Ntot;
-  int tm, tn, wave, lane;
+  float* slab; int ldn;         // this workgroup's slab tile origin and row pitch
+  int tm, cb0, wave, lane;      // cb0: first B column block of this workgroup
   long bt; int t;               // token tiles (bt, t), (bt, t + 1) of the k-step being issued
   const char *a, *b;
   __device__ __forceinline__ void advance() {
     t += 2;
     if (t >= T) { t = 0; ++bt; }
-    const int tt = wave >> 2, cbl = 2 * (wave & 3);        // this wave's tiles: token tile tt, column blocks cbl, cbl + 1
-    a = dG.base + dG.tile(bt, t + tt, tm * 8 + cbl, 0);
-    const int cbg = tn * 8 + cbl;
+    const int tt = wave >> 2;                               // this wave's token tile of the pair
+    a = dG.base + dG.tile(bt, t + tt, tm * 8 + 2 * (wave & 3), 0);
+    const int cbg = cb0 + (NTW == 8 ? 2 * (wave & 3) : (wave & 3));
     if (cbg < ncb_x) b = X.base + X.tile(bt, t + tt, cbg, 0);
     else if (cbg - ncb_x < ncb_h) b = Hs.base + Hs.tile(bt, t + tt, cbg - ncb_x, 0);
     else b = nullptr;
   }
-  // li = 4 * wave + q: column block cbl + (q >> 1), plane q & 1: four consecutive KiB
+  // A: li = 4 * wave + q: column blocks 2 (wave & 3) + (q >> 1), plane q & 1: four consecutive KiB.
+  // B: NTW 8 the same; NTW 4: li = 2 * wave + q: column block wave & 3, plane q.
   __device__ __forceinline__ const char* a_tile(int li) const { return a + (li & 3) * TILE_B; }
-  __device__ __forceinline__ const char* b_tile(int li) const { return b != nullptr ? b + (li & 3) * TILE_B : zero; }
-  __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) {
+  __device__ __forceinline__ const char* b_tile(int li) const {
+    return b != nullptr ? b + (li & (NTW == 8 ? 3 : 1)) * TILE_B : zero;
+  }
+  __device__ __forceinline__ void flush(f32x4 (&acc)[4][NTW]) {
     const int wm = wave >> 1, wn = wave & 1, r = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int row = tm * 256 + (wm * 4 + mt) * 16 + 4 * g + reg;
-          const int col = tn * 256 + (wn * 8 + nt) * 16 + r;
-          slab[(long)row * Ntot + col] = acc[mt][nt][reg];
+          const int col = (wn * NTW + nt) * 16 + r;
+          slab[(long)row * ldn + col] = acc[mt][nt][reg];
         }
   }
 };
 
-__global__ __launch_bounds__(512) void wgrad_planes_kernel(SeqPlanes dG, SeqPlanes X, SeqPlanes Hs, int T, int ncb_x,
-                                                           int ncb_h, const char* zero, float* slabs, int M, int Ntot,
-                                                           int nsteps_all, int ksplit) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tiles_m = M / gp::TM, tiles_n = Ntot / gp::TN, per = tiles_m * tiles_n;
-  // slices of one XCD's share sit on that XCD together with all their tiles: an operand tile is fetched from HBM
-  // once and served to the other workgroups of its slice by the L2
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int z = (j / per) * 8 + xcd, tile = j % per;
-  if (z >= ksplit) return;
-  const int chunk = (nsteps_all + ksplit - 1) / ksplit;
-  const int s0 = z * chunk;
-  const int n = min(chunk, nsteps_all - s0);
-  WgradPol pol;
+// Plan of a launch: per XCD `fa` k-slices of the full column tiles (each slice = tiles_m x nfull workgroups) and
+// `ha` k-slices of the half tile (tiles_m workgroups each); slices of one XCD's share sit on that XCD together with
+// all their tiles, so an operand tile is fetched from HBM once and served to the slice's other workgroups by the L2.
+struct WgradPlan {
+  int M, nfull, has_half, fa, ha, nsteps;
+  __host__ __device__ int ncols_full() const { return nfull * 256; }
+  int grid() const { return 8 * (fa * (M / 256) * nfull + ha * (M / 256) * has_half); }
+  size_t slab_floats() const { return (size_t)8 * fa * M * ncols_full() + (size_t)8 * ha * has_half * M * 128; }
+};
+
+template <int NTW>
+__device__ __forceinline__ void wgrad_run(SeqPlanes dG, SeqPlanes X, SeqPlanes Hs, int T, int ncb_x, int ncb_h,
+                                          const char* zero, float* slab, int ldn, int tm, int cb0, int s0, int n, char* lds) {
+  WgradPol<NTW> pol;
   pol.dG = dG; pol.X = X; pol.Hs = Hs; pol.T = T; pol.ncb_x = ncb_x; pol.ncb_h = ncb_h; pol.zero = zero;
-  pol.slab = slabs + (long)z * M * Ntot; pol.Ntot = Ntot;
-  pol.tm = tile / tiles_n; pol.tn = tile % tiles_n;
+  pol.slab = slab; pol.ldn = ldn; pol.tm = tm; pol.cb0 = cb0;
   pol.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   pol.lane = threadIdx.x & 63;
   const long idx = 2L * s0 - 2;                // advance() steps to 2 * s0 first
   pol.bt = idx >= 0 ? idx / T : -1;
   pol.t = idx >= 0 ? (int)(idx - pol.bt * T) : T - 2;
   if (n <= 0) {                                // an empty slice still owns a slab: zero it
-    f32x4 acc[4][8];
+    f32x4 acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int jj = 0; jj < NTW; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     pol.flush(acc);
     return;
   }
-  gp::mainloop<WgradPol, true>(pol, n, n, lds);
+  gp::mainloop<WgradPol<NTW>, true, NTW>(pol, n, n, lds);
+}
+
+__global__ __launch_bounds__(512) void wgrad_planes_kernel(SeqPlanes dG, SeqPlanes X, SeqPlanes Hs, int T, int ncb_x,
+                                                           int ncb_h, const char* zero, float* slabs, WgradPlan P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tiles_m = P.M / gp::TM, per = tiles_m * P.nfull;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  if (j < P.fa * per) {
+    const int ksplit = 8 * P.fa, z = (j / per) * 8 + xcd, tile = j % per;
+    const int chunk = (P.nsteps + ksplit - 1) / ksplit, s0 = z * chunk;
+    const int tm = tile / P.nfull, tn = tile % P.nfull, ldn = P.ncols_full();
+    wgrad_run<8>(dG, X, Hs, T, ncb_x, ncb_h, zero, slabs + (size_t)z * P.M * ldn + tn * 256, ldn, tm, tn * 8, s0,
+                 min(chunk, P.nsteps - s0), lds);
+  } else {
+    const int jj = j - P.fa * per;
+    const int ksplit = 8 * P.ha, z = (jj / tiles_m) * 8 + xcd, tm = jj % tiles_m;
+    const int chunk = (P.nsteps + ksplit - 1) / ksplit, s0 = z * chunk;
+    float* half = slabs + (size_t)8 * P.fa * P.M * P.ncols_full() + (size_t)z * P.M * 128;
+    wgrad_run<4>(dG, X, Hs, T, ncb_x, ncb_h, zero, half, 128, tm, P.nfull * 8, s0, min(chunk, P.nsteps - s0), lds);
+  }
 }
 
 // dw_ih[gate_major(m')][c] (+)= sum_z slab[z][m'][c], c < F;  dw_hh[gate_major(m')][j] (+)= sum_z slab[z][m'][Fp + j]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int M, int Ntot,
-                                                           int F, int Fp, int H, float* __restrict__ dw_ih,
-                                                           float* __restrict__ dw_hh, int accumulate) {
-  const long total = (long)M * (Fp + H);
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, WgradPlan P, int F, int Fp,
+                                                           int H, float* __restrict__ dw_ih, float* __restrict__ dw_hh,
+                                                           int accumulate) {
+  const long total = (long)P.M * (Fp + H);
+  const int nfc = P.ncols_full();
+  const float* halves = slabs + (size_t)8 * P.fa * P.M * nfc;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int m = i / (Fp + H), n = i % (Fp + H);
     if (n >= F && n < Fp) continue;
-    const float* p = slabs + (long)m * Ntot + n;
+    const bool full = n < nfc;
+    const float* p = full ? slabs + (long)m * nfc + n : halves + (long)m * 128 + (n - nfc);
+    const long pitch = full ? (long)P.M * nfc : (long)P.M * 128;
+    const int ns = 8 * (full ? P.fa : P.ha);
     float s0 = 0.f, s1 = 0.f;
     int z = 0;
-    for (; z + 1 < ksplit; z += 2) {
-      s0 += p[(long)z * M * Ntot];
-      s1 += p[(long)(z + 1) * M * Ntot];
+    for (; z + 1 < ns; z += 2) {
+      s0 += p[z * pitch];
+      s1 += p[(z + 1) * pitch];
     }
-    if (z < ksplit) s0 += p[(long)z * M * Ntot];
+    if (z < ns) s0 += p[z * pitch];
     const float s = s0 + s1;
     const int row = gate_major(m, H);
     float* dst = n < F ? dw_ih + (long)row * F + n : dw_hh + (long)row * H + (n - Fp);
@@ -328,43 +358,55 @@ int vts_planes_dgrad(const void* dg_planes, const float* w_ih, float* dx_t16, vo
   return VTS_OK;
 }
 
-// split-K plan of the paired weight gradients: column tiles over [Fp | H] padded to 256, slices in multiples of 8
-static void wgrad_plan(long B, long T, long F, long H, int* Ntot, int* ksplit, int* nsteps) {
-  const int Fp = vts_planes_fpad(F);
-  *Ntot = (int)((Fp + H + 255) / 256 * 256);
-  const int per = (int)(4 * H / 256) * (*Ntot / 256);
-  *nsteps = (int)(B / 16 * T / 2);
-  int ks = 8 * ((grid_cus() / 8) / per);
-  if (ks < 8) ks = 8;
-  while (ks > 8 && *nsteps / ks < 8) ks -= 8;
-  *ksplit = ks;
+// Split-K plan of the paired weight gradients.  Column blocks of [Fp | H]: full tiles of eight, and a half tile
+// when at most four remain.  Per XCD (a share of cus / 8 CUs) fa slices of the full tiles and ha of the half tile are
+// chosen so that every workgroup is resident at once and both kinds finish together (a half-tile k-step is taken as
+// 0.6 of a full one: half the matrix work, three quarters of the loads).
+static WgradPlan wgrad_plan(long B, long T, long F, long H) {
+  WgradPlan P{};
+  P.M = (int)(4 * H);
+  const int ncb = vts_planes_fpad(F) / 32 + (int)(H / 32);
+  P.nfull = ncb / 8;
+  const int rem = ncb % 8;
+  P.has_half = 0;
+  if (rem > 4) P.nfull += 1;
+  else if (rem > 0) P.has_half = 1;
+  P.nsteps = (int)(B / 16 * T / 2);
+  const int tiles_m = P.M / 256, share = grid_cus() / 8;
+  double best = 1e30;
+  P.fa = 1; P.ha = P.has_half;
+  for (int fa = 1; fa * tiles_m * P.nfull <= share; ++fa)
+    for (int ha = P.has_half; ha <= (P.has_half ? share : 0); ++ha) {
+      if (fa * tiles_m * P.nfull + ha * tiles_m * P.has_half > share) break;
+      if (P.nsteps / (8 * fa) < 4) continue;
+      const double tf = (double)P.nsteps / (8 * fa), th = P.has_half ? 0.6 * P.nsteps / (8 * ha) : 0.0;
+      const double t = tf > th ? tf : th;
+      if (t < best) { best = t; P.fa = fa; P.ha = ha; }
+    }
+  return P;
 }
 size_t vts_planes_wgrad_slab_bytes(long B, long T, long F, long H) {
-  int Ntot, ksplit, nsteps;
-  wgrad_plan(B, T, F, H, &Ntot, &ksplit, &nsteps);
-  return (size_t)ksplit * 4 * H * Ntot * sizeof(float);
+  return wgrad_plan(B, T, F, H).slab_floats() * sizeof(float);
 }
 
 // dw_ih[4H, F] (+)= dG^T . S,  dw_hh[4H, H] (+)= dG^T . h(one step back): one launch + the slab reduction.
 // x_zero_slot: S is an h sequence (slot 0 = zeros) rather than a converted input.
 int vts_planes_wgrad(const void* dg_planes, const void* s_planes, int x_zero_slot, const void* h_planes, float* dw_ih,
                      float* dw_hh, int accumulate, float* slabs, long B, long T, long F, long H, hipStream_t st) {
-  int Ntot, ksplit, nsteps;
-  wgrad_plan(B, T, F, H, &Ntot, &ksplit, &nsteps);
-  const int M = (int)(4 * H), Fp = vts_planes_fpad(F);
+  const WgradPlan P = wgrad_plan(B, T, F, H);
+  const int Fp = vts_planes_fpad(F);
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(wgrad_planes_kernel), gp::LDS_B, &g_lds_wgrad, "wgrad_planes")) return rc;
-  SeqPlanes dG = seq_planes(const_cast<void*>(dg_planes), T, M, 0);
+  SeqPlanes dG = seq_planes(const_cast<void*>(dg_planes), T, P.M, 0);
   SeqPlanes X = seq_planes(const_cast<void*>(s_planes), T, F, x_zero_slot);
   SeqPlanes Hs = seq_planes(const_cast<void*>(h_planes), T, H, 1);
   Hs.t0 = 0;                                        // slot t = h_{t-1}; slot 0 = the zero initial state
   const char* zero = Hs.base;                       // (bt 0, slot 0, cb 0): 2 KiB of zeros
-  const int per = (M / 256) * (Ntot / 256);
-  hipLaunchKernelGGL(wgrad_planes_kernel, dim3(8 * (ksplit / 8) * per), dim3(512), gp::LDS_B, st, dG, X, Hs, (int)T,
-                     Fp / 32, (int)(H / 32), zero, slabs, M, Ntot, nsteps, ksplit);
+  hipLaunchKernelGGL(wgrad_planes_kernel, dim3(P.grid()), dim3(512), gp::LDS_B, st, dG, X, Hs, (int)T, Fp / 32,
+                     (int)(H / 32), zero, slabs, P);
   VTS_CHECK_LAUNCH("wgrad_planes");
-  const long total = (long)M * (Fp + H);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, ksplit, M, Ntot,
-                     (int)F, Fp, (int)H, dw_ih, dw_hh, accumulate);
+  const long total = (long)P.M * (Fp + H);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, P, (int)F, Fp,
+                     (int)H, dw_ih, dw_hh, accumulate);
   VTS_CHECK_LAUNCH("wgrad_reduce");
   return VTS_OK;
 }

@@ -388,6 +388,278 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 #endif
 }
 
+
+// ---- backward ---------------------------------------------------------------------------------------------
+// Reverse recurrence with W_hh stationary, same clusters: member c owns hidden units [32c, 32c + 32).  Per step it
+// turns the running gradients of its slice into the gate gradients dA_t[:, 128 columns of its slice] (cell
+// backward, lane-local), and needs dh_{t-1}[:, its slice] = dA_t[:, all 1024 columns] . W_hh[:, its slice]: the
+// weight slice (1024 x 32, hi and lo planes, 128 KiB) stays in LDS, and what the members exchange is dA - through
+// the very buffer the layer's products read afterwards: every member writes its tiles of the gate-gradient planes
+// (gemm_planes.h; the output this kernel owes anyway) with sc1 stores and reads its peers' tiles of the same step
+// back with sc1 loads once their flags are up.  No exchange buffer, no extra HBM bytes; every step has its own
+// tiles, so nothing is ever reused while a peer may still read it.  Column order of the planes: k' = 4 * hidden +
+// gate, as the one-workgroup kernel writes them.
+constexpr int KSB = 4 * CH / 32;                       // k-steps of the backward product
+constexpr int WB_LDS = KSB * 2 * 2 * 1024;             // resident slice: [ks][hi | lo][ct 2][64 lanes] x 16 B = 128 KiB
+constexpr int SB_WAVE = 4 * 1024;                      // per-wave staging: 16 windows x 64 columns as 2 tiles x 2 planes
+constexpr int CB_LDS = WB_LDS + 4 * SB_WAVE;           // 144 KiB
+
+// image: [member c][ks][hi | lo][ct][lane] -> W_hh[gate_major(k')][(2c + ct)*16 + (lane & 15)], k' = 32 ks + 8 (lane >> 4) + e
+__global__ void pack_whh3cb_kernel(const float* __restrict__ W, u32x4* __restrict__ out) {
+  const int total = CH * CH;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int ct = rest & 1; rest >>= 1;
+    const int p = rest & 1; rest >>= 1;
+    const int ks = rest & (KSB - 1);
+    const int c = rest >> 5;
+    const int col = (2 * c + ct) * 16 + (lane & 15);
+    const int k0 = 32 * ks + 8 * (lane >> 4);
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ka = k0 + 2 * q, kb = ka + 1;
+      unsigned hi, lo;
+      split2(W[((ka & 3) * CH + (ka >> 2)) * CH + col], W[((kb & 3) * CH + (kb >> 2)) * CH + col], hi, lo);
+      o[q] = p ? lo : hi;
+    }
+    out[idx] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void lstm_rec3c_bwd_kernel(
+    const float* __restrict__ G, const float* __restrict__ cseq, const float* __restrict__ dhseq,
+    const float* __restrict__ dhlast, const float* __restrict__ dclast, float* __restrict__ dbpart,
+    const u32x4* __restrict__ Wp, gp::SeqPlanes dgp, unsigned* __restrict__ flags, unsigned* __restrict__ err, int T,
+    int nclusters, int spin_limit, int mute_member) {
+  constexpr int JT = CH / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemc[];
+  u32x4* wl = reinterpret_cast<u32x4*>(smemc);                 // [ks][plane][ct][lane]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* stage = smemc + WB_LDS + wave * SB_WAVE;      // this wave's own
+  const int r = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int c = j & 7;
+  const int q = (j >> 3) * 8 + xcd;
+  if (q >= nclusters) return;
+  {
+    const u32x4* src = Wp + (size_t)c * (WB_LDS / 16);
+#pragma unroll 4
+    for (int i = tid; i < WB_LDS / 16; i += 256) wl[i] = src[i];
+  }
+  // the cluster's window tiles of the gate-gradient planes as one buffer: [rt 8][t][cb 32][plane 2] tiles of 1 KiB
+  const long cl_bytes = 8L * dgp.ts * dgp.ncb * 2 * gp::TILE_B;
+  const __amdgpu_buffer_rsrc_t prsrc =
+      __builtin_amdgcn_make_buffer_rsrc(dgp.base + (size_t)q * cl_bytes, 0, (int)cl_bytes, 0x00020000);
+  auto tile_off = [&](int rt, int t, int cb, int p) -> int {
+    return (((rt * dgp.ts + t) * dgp.ncb + cb) * 2 + p) * gp::TILE_B;
+  };
+  unsigned* fw = flags + ((size_t)q * 4 + wave) * NC * FLAG_STRIDE;     // [cluster][wave][member]
+  const unsigned pl_off = gp::slot(g, r) * 16;
+  bool wdead = false;
+
+  // running gradients of this lane's 2 x 2 blocks (window tile 2 wave + mt, hidden tile 2 c + jl)
+  f32x4 dc[2][2], dh[2][2];
+  float dbs[2][2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl) {
+      const long blk = (((long)q * 8 + 2 * wave + mt) * JT + 2 * c + jl) * 256 + lane * 4;
+      dh[mt][jl] = dhlast != nullptr ? *reinterpret_cast<const f32x4*>(dhlast + blk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      dc[mt][jl] = dclast != nullptr ? *reinterpret_cast<const f32x4*>(dclast + blk) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dbs[mt][jl][k] = 0.f;
+    }
+
+  // saved tensors of a step, 24 blocks of 16 bytes per lane: part 0..15 gates (mt, gate, jl), 16..19 c_{t-1},
+  // 20..23 the upstream gradient of the h sequence
+  f32x4 gn[2][4][2], cprev[2][2], ccur[2][2], dn[2][2];
+  auto load_part = [&](int t, int part) {
+    if (part < 16) {
+      const int mt = part >> 3, gate = (part >> 1) & 3, jl = part & 1;
+      const long bt = (long)q * 8 + 2 * wave + mt;
+      gn[mt][gate][jl] = ld_stream(G + ((bt * T + t) * (4 * JT) + gate * JT + 2 * c + jl) * 256 + lane * 4);
+    } else {
+      const int mt = (part >> 1) & 1, jl = part & 1;
+      const long bt = (long)q * 8 + 2 * wave + mt;
+      if (part < 20) {
+        cprev[mt][jl] = t > 0 ? ld_stream(cseq + ((bt * T + t - 1) * JT + 2 * c + jl) * 256 + lane * 4)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        dn[mt][jl] = dhseq != nullptr ? ld_stream(dhseq + ((bt * T + t) * JT + 2 * c + jl) * 256 + lane * 4)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+      ccur[mt][jl] = ld_stream(cseq + ((((long)q * 8 + 2 * wave + mt) * T + T - 1) * JT + 2 * c + jl) * 256 + lane * 4);
+  static_for<24>([&](auto pc) { load_part(T - 1, decltype(pc)::value); });
+  __syncthreads();   // weight slice in place
+
+#ifdef VTS_CB_STAMP
+  long long bstamp[4] = {0, 0, 0, 0};
+  long long bprev = clock64();
+#define BSTAMP(i) do { const long long now = clock64(); bstamp[i] += now - bprev; bprev = now; } while (0)
+#else
+#define BSTAMP(i)
+#endif
+  for (int t = T - 1; t >= 0; --t) {
+    BSTAMP(3);
+    if (t < T - 1) {
+      // ---- wait until wave `wave` of every member has published its rows of dA_{t+1} (flag = steps published).
+      // The waves of a workgroup do not wait for each other: a wave's product reads only the window rows that the
+      // same-numbered waves of the eight members wrote.
+      {
+        int spins = 0;
+        bool ok = false;
+        const unsigned want = (unsigned)(T - 1 - t);
+        do {
+          const unsigned seen = lane < NC ? __hip_atomic_load(fw + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0xffffffffu;
+          ok = __all(seen >= want);
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(1);
+        } while (++spins < spin_limit);
+        if (!ok) {
+          if (lane == 0) atomicOr(err, 1u);
+          wdead = true;
+          break;
+        }
+      }
+      BSTAMP(0);
+      // ---- dh_t[:, slice] = dA_{t+1} . W_hh[:, slice]: A fragments from the planes (own tiles included), seven
+      // k-steps ahead in an eight-slot rotation (28 KiB per wave in flight: the L2 round trip is ~1 us and a step
+      // has 128 KiB per wave to pull); the weight fragments from LDS two groups ahead; the saved tensors of step t
+      // ride along, one block per k-step
+      u32x4 a[8][2][2];
+      auto load_a = [&](int ks) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            a[ks & 7][mt][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                prsrc, tile_off(2 * wave + mt, t + 1, ks, p) + pl_off, 0, 16));
+      };
+      static_for<7>([&](auto kc) { load_a(decltype(kc)::value); });
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x4 bh[3], bl[3];
+      auto fetch_b = [&](int idx, int sl) {
+        bh[sl] = wl[(((idx >> 1) * 2 + 0) * 2 + (idx & 1)) * 64 + lane];
+        bl[sl] = wl[(((idx >> 1) * 2 + 1) * 2 + (idx & 1)) * 64 + lane];
+      };
+      fetch_b(0, 0);
+      fetch_b(1, 1);
+      static_for<KSB * 2>([&](auto idx_c) {
+        constexpr int idx = decltype(idx_c)::value;
+        constexpr int ks = idx >> 1, ct = idx & 1, sl = idx % 3;
+        if (idx + 2 < KSB * 2) fetch_b(idx + 2, (idx + 2) % 3);
+        if (ct == 0) {
+          if (ks + 7 < KSB) load_a(ks + 7);
+        } else {
+          if (ks < 24) load_part(t, ks);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks & 7][mt][1]), frag(bh[sl]), acc[mt][ct], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks & 7][mt][0]), frag(bl[sl]), acc[mt][ct], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks & 7][mt][0]), frag(bh[sl]), acc[mt][ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) dh[mt][jl] = acc[mt][jl];
+      BSTAMP(1);
+    }
+
+    // ---- cell backward of step t, one 16 x 16 block at a time: gate gradients -> this wave's staging tiles (the
+    // plane tile format, four gates of a hidden unit = 8 bytes per plane) -> 16-byte fragments -> the planes
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int jl = 0; jl < 2; ++jl) {
+        const f32x4 gi = gn[mt][0][jl], gf = gn[mt][1][jl], gg = gn[mt][2][jl], go = gn[mt][3][jl];
+        const f32x4 ct_ = ccur[mt][jl], cp = cprev[mt][jl];
+        const f32x4 dht = dh[mt][jl] + dn[mt][jl];
+        f32x4 dai, daf, dag, dao;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float tc = fast_tanh(ct_[reg]);
+          const float d_o = dht[reg] * tc;
+          const float dcc = dc[mt][jl][reg] + dht[reg] * go[reg] * (1.f - tc * tc);
+          const float d_i = dcc * gg[reg];
+          const float d_g = dcc * gi[reg];
+          const float d_f = dcc * cp[reg];
+          dc[mt][jl][reg] = dcc * gf[reg];
+          dai[reg] = d_i * gi[reg] * (1.f - gi[reg]);
+          daf[reg] = d_f * gf[reg] * (1.f - gf[reg]);
+          dag[reg] = d_g * (1.f - gg[reg] * gg[reg]);
+          dao[reg] = d_o * go[reg] * (1.f - go[reg]);
+          uint2 hi, lo;
+          split4(dai[reg], daf[reg], dag[reg], dao[reg], hi, lo);
+          // element (window row 4 g + reg, column 4 r + gate of the block's 64) -> tile r >> 3, k = 4 (r & 7) + gate
+          const int row = 4 * g + reg;
+          const int off = (r >> 3) * (2 * gp::TILE_B) + gp::slot((r & 7) >> 1, row) * 16 + (r & 1) * 8;
+          *reinterpret_cast<uint2*>(stage + off) = hi;
+          *reinterpret_cast<uint2*>(stage + gp::TILE_B + off) = lo;
+        }
+        dbs[mt][jl][0] += (dai[0] + dai[1]) + (dai[2] + dai[3]);
+        dbs[mt][jl][1] += (daf[0] + daf[1]) + (daf[2] + daf[3]);
+        dbs[mt][jl][2] += (dag[0] + dag[1]) + (dag[2] + dag[3]);
+        dbs[mt][jl][3] += (dao[0] + dao[1]) + (dao[2] + dao[3]);
+        // the wave reads back what it alone wrote (LDS operations of a wave execute in order)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {      // i = tile (r >> 3) * 2 + plane
+          const u32x4 v = *reinterpret_cast<const u32x4*>(stage + i * gp::TILE_B + lane * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, v), prsrc,
+                                                 tile_off(2 * wave + mt, t, 4 * c + 2 * jl + (i >> 1), i & 1) + lane * 16, 0, 16);
+        }
+        ccur[mt][jl] = cp;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    BSTAMP(2);
+    if (t > 0) {
+      // ---- publish: this wave's stores drained, then its flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0 && c != mute_member)
+        __hip_atomic_store(fw + c * FLAG_STRIDE, (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+#ifdef VTS_CB_STAMP
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 4; ++i) reinterpret_cast<long long*>(err + 2)[i] = bstamp[i];
+#endif
+  // bias-gradient partials: sum over the 4 row groups (lanes r, r+16, r+32, r+48); poisoned after a timeout
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float s = dbs[mt][jl][k];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (wdead) s = __builtin_nanf("");
+        if (g == 0) dbpart[((long)q * 8 + 2 * wave + mt) * (4 * CH) + k * CH + (2 * c + jl) * 16 + r] = s;
+      }
+}
+
 }  // namespace
 
 // The cluster kernel serves the bench-sized launches: hidden 256, whole clusters, and a grid that is resident
@@ -465,5 +737,58 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
   hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(grid), dim3(256), C_LDS, stream, G, cseq, hseq, hlast, clast, img, xchg,
                      flags, err, T, nclusters, spin_limit, mute_member, hp);
   VTS_CHECK_LAUNCH("lstm_rec3c_fwd");
+  return VTS_OK;
+}
+
+size_t vts_lstm_rec3c_bwd_flag_bytes(int B) { return (size_t)(B / CROWS) * 4 * NC * FLAG_STRIDE * sizeof(unsigned); }
+
+// Backward counterpart: same contract as vts_lstm_rec3c_fwd (VTS_ERR_UNSUPPORTED with nothing launched when the
+// grid cannot be guaranteed resident).  dhlast / dclast are tile16 [B, 256] blocks or null; dg_planes is the
+// gate-gradient plane buffer (T step slots per window tile, 32 column blocks); fws holds the flag words.
+int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+                       float* dbpart, const float* W_hh, float* Wp, void* dg_planes, void* fws, unsigned* err, int B, int T,
+                       hipStream_t stream) {
+  const int nclusters = B / CROWS;
+  static vts_lds_mask lds_done{0};
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_bwd_kernel), CB_LDS, &lds_done, "lstm_rec3c_bwd"))
+    return rc;
+  const unsigned grid = 64 * vts_cdiv(nclusters, 8);
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(lstm_rec3c_bwd_kernel), 256,
+                                                   CB_LDS) != hipSuccess ||
+      (long)per_cu * cus < (long)grid) {
+    (void)hipGetLastError();
+    vts_set_error("lstm_rec3c_bwd: %u workgroups cannot be resident at once (%d per CU x %d CUs)", grid, per_cu, cus);
+    return VTS_ERR_UNSUPPORTED;
+  }
+  u32x4* img = reinterpret_cast<u32x4*>(Wp);
+  hipLaunchKernelGGL(pack_whh3cb_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img);
+  VTS_CHECK_LAUNCH("pack_whh3cb");
+  unsigned* flags = reinterpret_cast<unsigned*>(fws);
+  if (hipMemsetAsync(flags, 0, vts_lstm_rec3c_bwd_flag_bytes(B), stream) != hipSuccess) {
+    vts_set_error("lstm_rec3c_bwd: clearing the hand-off flags failed");
+    return VTS_ERR_HIP;
+  }
+  int mute_member = g_fault_member.load();
+  int spin_limit = mute_member >= 0 ? 1 << 10 : 1 << 21;
+  int nc = nclusters;
+  gp::SeqPlanes dgp{reinterpret_cast<char*>(dg_planes), 32, T, 0};
+  static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return !(e && e[0] == '0'); }();
+  if (coop) {
+    void* args[] = {&G, &cseq, &dhseq, &dhlast, &dclast, &dbpart, &img, &dgp, &flags, &err, &T, &nc, &spin_limit, &mute_member};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_rec3c_bwd_kernel), dim3(grid),
+                                                    dim3(256), args, CB_LDS, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      vts_set_error("lstm_rec3c_bwd: cooperative launch refused: %s", hipGetErrorString(e));
+      return e == hipErrorCooperativeLaunchTooLarge ? VTS_ERR_UNSUPPORTED : VTS_ERR_HIP;
+    }
+    return VTS_OK;
+  }
+  hipLaunchKernelGGL(lstm_rec3c_bwd_kernel, dim3(grid), dim3(256), CB_LDS, stream, G, cseq, dhseq, dhlast, dclast, dbpart,
+                     img, dgp, flags, err, T, nclusters, spin_limit, mute_member);
+  VTS_CHECK_LAUNCH("lstm_rec3c_bwd");
   return VTS_OK;
 }

@@ -1,6 +1,7 @@
 // extern "C" surface of libvts_hip.so (declared in include/vts.h): argument checks, workspace
 // carving and kernel sequencing.  No device allocation, no synchronisation.
 #include "vts_common.h"
+#include <atomic>
 #include "../../include/vts.h"
 #include <math.h>
 #include <string.h>
@@ -69,6 +70,10 @@ int vts_planes_wgrad(const void* dg_planes, const void* s_planes, int x_zero_slo
                      float* dw_hh, int accumulate, float* slabs, long B, long T, long F, long H, hipStream_t st);
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
                        void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream);
+size_t vts_lstm_rec3c_bwd_flag_bytes(int B);
+int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+                       float* dbpart, const float* W_hh, float* Wp, void* dg_planes, void* fws, unsigned* err, int B, int T,
+                       hipStream_t stream);
 int vts_lstm_rec3_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
                       float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, void* dg_planes,
                       hipStream_t stream);
@@ -178,10 +183,11 @@ static size_t rec_ws_dbpart_bytes(int64_t B, int64_t H) {
 }
 static size_t rec_ws_seed_bytes(int64_t B, int64_t H) { return round256((size_t)pad16(B) * H * sizeof(float)); }
 // [packed W_hh image][bias-gradient partials][dh_T in tile16 order][dc_T in tile16 order]
-// ... [status word of the forward launch, 256 B]
+// ... [status word of the launch, 256 B][hand-off flags of the backward cluster kernel: four 128-byte lines per 16 windows]
+static size_t rec_ws_bflag_bytes(int64_t B) { return round256((size_t)(pad16(B) / 16) * 512); }
 size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
   (void)T;
-  return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H) + 256;
+  return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H) + 256 + rec_ws_bflag_bytes(B);
 }
 static unsigned* rec_ws_status(void* workspace, int64_t B, int64_t H) {
   return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) +
@@ -294,6 +300,9 @@ int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_las
                             nullptr, stream);
 }
 
+static std::atomic<int> g_cluster_bwd{[] { const char* e = getenv("VTS_LSTM_CLUSTER_BWD"); return (e && e[0] == '1') ? 1 : 0; }()};
+void vts_debug_set_cluster_bwd(int on) { g_cluster_bwd.store(on ? 1 : 0); }
+
 static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
                               const float* dc_last, const float* w_hh, float* db_ih, float* db_hh, int accumulate,
                               void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
@@ -318,6 +327,24 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
     float* seed_c = dc_last ? reinterpret_cast<float*>(seed + rec_ws_seed_bytes(B, H)) : nullptr;
     if (seed_h) VTS_RC(vts_ew_tile16_convert(dh_last, seed_h, (int)B, 1, (int)H, 0, st));
     if (seed_c) VTS_RC(vts_ew_tile16_convert(dc_last, seed_c, (int)B, 1, (int)H, 0, st));
+    // plane output at bench size: W_hh stationary in clusters of eight workgroups, as the forward pass; when the
+    // runtime will not guarantee a resident grid nothing was launched and the one-workgroup kernel takes over
+    // (Off unless asked for - VTS_LSTM_CLUSTER_BWD=1 at start-up or vts_debug_set_cluster_bwd(1): measured at
+    // 4096 x 96, hidden 256, it is 3 % slower than the one-workgroup kernel.  Its members exchange dA, four
+    // times the forward kernel's h, and a CU's vector memory pipe moves the 610 KiB a step then needs no faster
+    // than the 1 MiB weight image of the one-workgroup kernel.)
+    int rc = VTS_ERR_UNSUPPORTED;
+    if (dg_planes && g_cluster_bwd.load() > 0 && vts_lstm_rec3c_usable((int)B, (int)T, (int)H)) {
+      unsigned* status = rec_ws_status(workspace, B, H);
+      if (hipMemsetAsync(status, 0, sizeof(unsigned), st) != hipSuccess) {
+        vts_set_error("lstm_recurrent_bwd: clearing the status word failed");
+        return VTS_ERR_HIP;
+      }
+      rc = vts_lstm_rec3c_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, dg_planes,
+                              reinterpret_cast<char*>(status) + 256, status, (int)B, (int)T, st);
+      if (rc != VTS_OK && rc != VTS_ERR_UNSUPPORTED) return rc;
+    }
+    if (rc == VTS_ERR_UNSUPPORTED)
     VTS_RC(vts_lstm_rec3_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, (int)B, (int)T, (int)H,
                              dg_planes, st));
   } else {

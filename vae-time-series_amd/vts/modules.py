@@ -311,8 +311,14 @@ class _Site:
     counter hash from a fresh seed (training), or absent (eval)."""
 
     def __init__(self, noise: Noise, key: str, training: bool):
-        self.keep = noise.get(key) if noise is not None else None
-        self.seed = F.new_seed() if (self.keep is None and training and noise is None) else 0
+        entry = noise.get(key) if noise is not None else None
+        if entry is False:        # the site is switched off explicitly (fixtures recorded without that draw)
+            self.keep, self.seed = None, 0
+            return
+        self.keep = entry
+        # keyed on this site's own entry: a noise dict that feeds only some draws (eps / u / choice, say) must not
+        # switch dropout off at the sites it does not mention
+        self.seed = F.new_seed() if (self.keep is None and training) else 0
 
 
 class SelfAttention(nn.Module):
