@@ -172,14 +172,16 @@ def wptr(t: torch.Tensor):
 class KernelTimer:
     """Brackets selected C-ABI calls with HIP events on torch's current stream (the stream the
     kernels are enqueued on) and accumulates device time per call name.  Used by bench.py to
-    measure the dominant kernels inside the timed region; off by default."""
+    measure the dominant kernels inside the timed region; off by default.  `only`: a set of call names to bracket
+    (None = all of them); every bracket puts two markers into the queue, a few microseconds of idle device each."""
 
     def __init__(self):
         self.records = []   # (name, start_event, end_event)
         self.enabled = False
+        self.only = None
 
     def call(self, name, fn, *args):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and name not in self.only):
             return fn(*args)
         start = torch.cuda.Event(enable_timing=True)
         end = torch.cuda.Event(enable_timing=True)
