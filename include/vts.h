@@ -181,6 +181,12 @@ void vts_debug_set_cluster_fault(int member);
  * unless VTS_LSTM_CLUSTER_BWD=1 is set at start-up) it runs one workgroup per 16 windows, which measures 3 %
  * faster.  Same results either way up to the order of fp32 sums. */
 void vts_debug_set_cluster_bwd(int on);
+/* Development switch, process-wide: on = 0 runs the bf16x3 backward recurrence at hidden 256 on the kernel that
+ * loads a step's saved gates, cells and dh straight into registers at the top of the step's product (the kernel the
+ * other hidden sizes use); on != 0 (default, unless VTS_LSTM_STAGED_BWD=0 is set at start-up) on the kernel that
+ * stages them through LDS a step ahead and keeps an eighth of the packed W_hh image in registers (5 % faster at
+ * the bench shape).  Same arithmetic in the same order: identical results. */
+void vts_debug_set_staged_bwd(int on);
 
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,

@@ -7,6 +7,9 @@ tools/bench_kernels.py --mode 1 --only recurrent_bwd --lib tools/ubench/librec_x
     3  no MFMAs
     4  no loads of the saved gates / cells / dh
     5  1 + 4: only MFMAs, cell arithmetic, LDS traffic, barriers
+    s  the library as it is, with the staged kernel's phase stamps compiled in (-DVTS_RB_STAMP; read them with
+       tools/ubench/rec_bwd_stamps.py)
+(1-5 patch lstm_rec3_bwd_kernel, the kernel VTS_LSTM_STAGED_BWD=0 selects.)
 """
 import os
 import re
@@ -44,13 +47,15 @@ def variant(n):
 
 
 objs = "vts_api.o gemm_f32.o lstm_rec_f32.o lstm_rec_cluster.o lstm_planes.o elementwise.o attention.o ffn_fused.o windows.o mixture3.o".split()
-for n in [int(x) for x in (sys.argv[1:] or "1 2 3 4 5".split())]:
-    p = os.path.join(CSRC, "_recx%d.hip" % n)
-    open(p, "w").write(variant(n))
-    o = "/tmp/recx/recx%d.o" % n
+os.makedirs("/tmp/recx", exist_ok=True)
+for n in (sys.argv[1:] or "1 2 3 4 5".split()):
+    p = os.path.join(CSRC, "_recx%s.hip" % n)
+    open(p, "w").write(src if n == "s" else variant(int(n)))
+    o = "/tmp/recx/recx%s.o" % n
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-                           "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-c", p, "-o", o], cwd=CSRC)
+                           "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-c", p, "-o", o]
+                          + (["-DVTS_RB_STAMP"] if n == "s" else []), cwd=CSRC)
     os.remove(p)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
-                           os.path.join(ROOT, "tools", "ubench", "librec_x%d.so" % n), o] + objs, cwd=CSRC)
+                           os.path.join(ROOT, "tools", "ubench", "librec_x%s.so" % n), o] + objs, cwd=CSRC)
     print("built", n)

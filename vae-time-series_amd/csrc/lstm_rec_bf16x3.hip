@@ -12,9 +12,15 @@
 // delivers the W_hh image to 32 CUs at once (~70 GB/s per CU), so part of the image stays in LDS.
 #include "lstm_rec_common.h"
 #include "gemm_planes.h"
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
+
+// hidden 256: the backward kernel that stages the saved gates through LDS (lstm_rec3_bwd_staged_kernel) unless
+// VTS_LSTM_STAGED_BWD=0 is in the environment (read once) or vts_lstm_rec3_set_staged_bwd(0) was called
+std::atomic<int> g_staged_bwd{[] { const char* e = getenv("VTS_LSTM_STAGED_BWD"); return e == nullptr || e[0] != '0' ? 1 : 0; }()};
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -535,6 +541,308 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
   }
 }
 
+// ---- backward, saved gates staged through LDS -----------------------------------------------------
+// Same product and cell arithmetic as lstm_rec3_bwd_kernel; what differs is when the step's saved tensors are
+// fetched.  Vector memory loads complete in issue order, so the 20-odd HBM loads of a step's gates, cells and dh,
+// issued at the top of a product, hold up every W_hh ring load issued behind them until the slowest of them is
+// back (a quarter of the kernel's time at the bench shape).  Here the batch for step t - 1 is issued at the start
+// of step t's cell phase, behind ring loads for the next product's first FOUR k-steps: the next ring load behind
+// the batch is consumed a whole cell phase and four k-steps later.  The gates travel by LDS-DMA into a per-wave
+// staging area (no registers, so the batch can fly while the cell phase still uses the previous one; the cell
+// phase first copies its gates from staging to registers, then issues the next batch), cells and dh into a second
+// set of registers by inline-asm loads.  dA is single-buffered in LDS to make room: two barriers per step.
+// DH: a dh sequence is given (four more loads per batch - the hand-counted waits need the count at compile time).
+// LDS: dA planes [hi, lo][16][4H] bf16, then staging [wave][JPW * 4 gate tiles][1 KiB].
+template <int H, bool PL, bool DH>
+__global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kernel(
+    float* __restrict__ G, const float* __restrict__ cseq, const float* __restrict__ dhseq,
+    const float* __restrict__ dhlast, const float* __restrict__ dclast, float* __restrict__ dbpart,
+    const u32x4* __restrict__ Wp, int B, int T, gp::SeqPlanes dgp) {
+  using C = RecCfg<H>;
+  using R = Rec3Cfg<H>;
+  constexpr int JPW = C::JPW;
+  constexpr int UT = 2 * JPW;                  // fragments per k-step and wave
+  constexpr int KS = R::KS_B;
+  constexpr int NB = 4 * JPW + JPW + (DH ? JPW : 0);   // loads per batch: gate tiles, cells, dh
+  constexpr bool RING_AG = false;              // (true: the allocator spills and writes into ring registers in flight)
+  constexpr int RES = 4;                       // k-steps of the image resident in registers
+  static_assert(KS % 4 == 0 && KS >= RES + 8, "ring of four k-steps, batch retired by the fifth streamed one");
+  static_assert(3 * UT + NB <= 63, "vmcnt is a six-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  constexpr int ROWB = 4 * H * 2;              // bytes per row of a plane
+  constexpr int PLANE = 16 * ROWB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int bt = blockIdx.x;
+  unsigned char* const da_s = smem3;
+  constexpr int STG = 6 * JPW * 1024;          // staging bytes per wave
+  unsigned char* const stg = smem3 + 2 * PLANE + wave * STG;
+  const unsigned stg_lds = __builtin_amdgcn_readfirstlane(gp::lds_addr(reinterpret_cast<const char*>(stg)));
+
+  f32x4 dc[JPW], dh[JPW];
+  float dbs[JPW][4];
+#pragma unroll
+  for (int jl = 0; jl < JPW; ++jl) {
+    const long blk = ((long)bt * C::JT + wave * JPW + jl) * 256 + lane * 4;
+    dh[jl] = dhlast != nullptr ? *reinterpret_cast<const f32x4*>(dhlast + blk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dc[jl] = dclast != nullptr ? *reinterpret_cast<const f32x4*>(dclast + blk) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dbs[jl][q] = 0.f;
+  }
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(Wp) + (size_t)wave * (KS * UT * 1024);
+  const unsigned voff = lane * 16;
+  const unsigned pl_off = gp::slot(g, r) * 16;
+  auto ks_ptr = [&](int ks) { return wbase + (size_t)(ks * UT) * 1024; };
+  // LDS traffic of this wave done, then the barrier.  Not lds_barrier(): with LDS-DMA in the kernel its release
+  // fence becomes s_waitcnt vmcnt(0), which would drain the ring and the batch in flight at every barrier.
+  auto wg_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // the batch of step t: G_t, c_{t-1} (c_0 when there is none: replaced by zeros when it is taken over) and dh_t by
+  // LDS-DMA into staging.  Always NB loads.
+  // LDS-DMA as inline asm: through the builtin the compiler knows that vector memory is writing LDS and puts
+  // s_waitcnt vmcnt(0) in front of the cell phase's first LDS write (and of every fenced barrier)
+  auto dma = [&](unsigned lds_off, const float* src) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_off), "v"(voff), "s"(src) : "memory", "m0");
+  };
+  auto issue_batch = [&](int t) {
+    const float* Gt = G + ((long)(bt * T + t) * (4 * C::JT) + wave * JPW) * 256;
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma(stg_lds + (jl * 4 + q) * 1024, Gt + (long)(q * C::JT + jl) * 256);
+    const int tc = t >= 1 ? t - 1 : 0;
+    const float* cb = cseq + ((long)(bt * T + tc) * C::JT + wave * JPW) * 256;
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) dma(stg_lds + (4 * JPW + jl) * 1024, cb + jl * 256);
+    if (DH) {
+      const float* db = dhseq + ((long)(bt * T + t) * C::JT + wave * JPW) * 256;
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl) dma(stg_lds + (5 * JPW + jl) * 1024, db + jl * 256);
+    }
+  };
+
+  f32x4 gn[JPW * 4], dn[JPW], cvt[JPW], cvp[JPW];
+#pragma unroll
+  for (int jl = 0; jl < JPW; ++jl)
+    cvt[jl] = ld_stream(cseq + ((long)(bt * T + T - 1) * C::JT + wave * JPW + jl) * 256 + lane * 4);
+
+  u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
+#pragma unroll
+  for (int i = 0; i < UT; ++i) w0[i] = w1[i] = w2[i] = w3[i] = u32x4{0u, 0u, 0u, 0u};
+  // k-steps 0..RES-1 of the image stay in registers for the whole sequence: an eighth less to stream per step
+  u32x4 wr[RES][UT];
+#pragma unroll
+  for (int i = 0; i < RES; ++i)
+#pragma unroll
+    for (int j = 0; j < UT; ++j)
+      wr[i][j] = *reinterpret_cast<const u32x4*>(ks_ptr(i) + j * 1024 + voff);
+  w_issue<UT, RING_AG>(w0, ks_ptr(RES + 0), voff);
+  w_issue<UT, RING_AG>(w1, ks_ptr(RES + 1), voff);
+  w_issue<UT, RING_AG>(w2, ks_ptr(RES + 2), voff);
+  w_issue<UT, RING_AG>(w3, ks_ptr(RES + 3), voff);
+  issue_batch(T - 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // staged gates -> registers, second register set -> first
+  auto take_over = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4 * JPW; ++i) gn[i] = *reinterpret_cast<const f32x4*>(stg + i * 1024 + lane * 16);
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      cvp[jl] = *reinterpret_cast<const f32x4*>(stg + (4 * JPW + jl) * 1024 + lane * 16);
+      if (t < 1) cvp[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dn[jl] = DH ? *reinterpret_cast<const f32x4*>(stg + (5 * JPW + jl) * 1024 + lane * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the copies are complete (and the staging area free) before the next batch may overwrite their sources
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto cell_bwd = [&](int t) {
+    float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
+    char* dg_t = PL ? dgp.base + dgp.tile(bt, t, 2 * wave * JPW, 0) + pl_off : nullptr;
+    u32x4 pf[4];
+    auto put_planes = [&](int jl) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)     // tile (k-step 2 * jl + (i >> 1), plane i & 1) of the wave's column blocks
+        __builtin_nontemporal_store(pf[i], reinterpret_cast<u32x4*>(dg_t + (4 * jl + i) * gp::TILE_B));
+    };
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) {
+      const int jt = wave * JPW + jl;
+      const f32x4 gi = gn[jl * 4 + 0], gf = gn[jl * 4 + 1], gg = gn[jl * 4 + 2], go = gn[jl * 4 + 3];
+      const f32x4 ct = cvt[jl], cp = cvp[jl];
+      const f32x4 dht = dh[jl] + dn[jl];
+      f32x4 dai, daf, dag, dao;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const float tc = fast_tanh(ct[reg]);
+        const float d_o = dht[reg] * tc;
+        const float dcc = dc[jl][reg] + dht[reg] * go[reg] * (1.f - tc * tc);
+        const float d_i = dcc * gg[reg];
+        const float d_g = dcc * gi[reg];
+        const float d_f = dcc * cp[reg];
+        dc[jl][reg] = dcc * gf[reg];
+        dai[reg] = d_i * gi[reg] * (1.f - gi[reg]);
+        daf[reg] = d_f * gf[reg] * (1.f - gf[reg]);
+        dag[reg] = d_g * (1.f - gg[reg] * gg[reg]);
+        dao[reg] = d_o * go[reg] * (1.f - go[reg]);
+        uint2 hi, lo;
+        split4(dai[reg], daf[reg], dag[reg], dao[reg], hi, lo);
+        const int row = 4 * g + reg;
+        const int j = jt * 16 + r;
+        const int off = row * ROWB + ((((j >> 1) ^ (row & 15)) << 4) | ((j & 1) << 3));
+        *reinterpret_cast<uint2*>(da_s + off) = hi;
+        *reinterpret_cast<uint2*>(da_s + PLANE + off) = lo;
+      }
+      dbs[jl][0] += (dai[0] + dai[1]) + (dai[2] + dai[3]);
+      dbs[jl][1] += (daf[0] + daf[1]) + (daf[2] + daf[3]);
+      dbs[jl][2] += (dag[0] + dag[1]) + (dag[2] + dag[3]);
+      dbs[jl][3] += (dao[0] + dao[1]) + (dao[2] + dao[3]);
+      if (!PL) {
+        st_stream(Gt + (long)(0 * C::JT + jt) * 256, dai);
+        st_stream(Gt + (long)(1 * C::JT + jt) * 256, daf);
+        st_stream(Gt + (long)(2 * C::JT + jt) * 256, dag);
+        st_stream(Gt + (long)(3 * C::JT + jt) * 256, dao);
+      } else {
+        // The plane tiles of this hidden tile (k-steps 2 * jt and 2 * jt + 1, both planes) are the wave's own LDS
+        // writes read back in fragment order - LDS operations of a wave execute in order, no barrier needed - and go
+        // out one hidden tile later, while the VALU works on the next one and the W_hh stream pauses anyway.
+        // (Stored from inside the k-steps, as the product reads the fragments, they cost the stream a tenth of
+        // its rate.)
+        if (jl > 0) put_planes(jl - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          pf[i] = *reinterpret_cast<const u32x4*>(da_s + (i & 1) * PLANE + r * ROWB + (((4 * (2 * jt + (i >> 1)) + g) ^ r) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (PL) put_planes(JPW - 1);
+  };
+
+  // (the last step's "next batch" is step 0 once more: an unconditional issue keeps the count of loads in the
+  // queue the same on every path, which is what the hand-counted waits - and their checker - rest on)
+#ifdef VTS_RB_STAMP
+  // timing experiments: ticks per phase, summed over the steps, written over the first bias-gradient partials
+  long long rstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long rprev = clock64();
+#define RSTAMP(i) do { const long long now = clock64(); rstamp[i] += now - rprev; rprev = now; } while (0)
+#else
+#define RSTAMP(i)
+#endif
+  take_over(T - 1);
+  issue_batch(T >= 2 ? T - 2 : 0);
+  cell_bwd(T - 1);
+#pragma unroll
+  for (int jl = 0; jl < JPW; ++jl) cvt[jl] = cvp[jl];
+  for (int t = T - 2; t >= 0; --t) {
+    RSTAMP(6);                                    // (cell backward of the step before)
+    wg_barrier();                                 // dA_{t+1} is complete
+    RSTAMP(0);
+    f32x4 acc[JPW];
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) acc[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto lds_a = [&](int plane, int ks) {
+      return *reinterpret_cast<const u32x4*>(da_s + plane * PLANE + r * ROWB + (((4 * ks + g) ^ r) << 4));
+    };
+    u32x4 ah = lds_a(0, RES), al = lds_a(1, RES);
+    // one k-step; kn = the k-step that runs next (its A fragments are fetched now); allowed < 0: a resident
+    // buffer, nothing to wait for
+    auto kstep = [&](u32x4 (&w)[UT], int ks, int kn, auto allowed) {
+      const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);
+      if constexpr (decltype(allowed)::value >= 0) w_wait<decltype(allowed)::value, UT, RING_AG>(w);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl)
+        acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), as_bf16x8(w[jl]), acc[jl], 0, 0, 0);
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl)
+        acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(w[JPW + jl]), acc[jl], 0, 0, 0);
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl)
+        acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(w[jl]), acc[jl], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ah = nh;
+      al = nl;
+    };
+    // On entry the queue holds, oldest first: w0 w1 w2 w3 (k-steps RES..RES+3, issued at the end of the previous
+    // product), then the batch of step t (NB loads).  Each streamed k-step waits for its buffer, then refills it
+    // four streamed k-steps ahead: three buffers (3 * UT loads) are younger than the one waited for, and during
+    // the first four so is the batch.  The resident k-steps run after those four (more time for the batch); the
+    // fifth streamed k-step's wait retires the batch.
+    constexpr std::integral_constant<int, 3 * UT> steady{};
+    constexpr std::integral_constant<int, 3 * UT + NB> first{};
+    constexpr std::integral_constant<int, -1> resident{};
+    kstep(w0, RES + 0, RES + 1, first);
+    w_issue<UT, RING_AG>(w0, ks_ptr(RES + 4), voff);
+    kstep(w1, RES + 1, RES + 2, first);
+    w_issue<UT, RING_AG>(w1, ks_ptr(RES + 5), voff);
+    kstep(w2, RES + 2, RES + 3, first);
+    w_issue<UT, RING_AG>(w2, ks_ptr(RES + 6), voff);
+    kstep(w3, RES + 3, 0, first);
+    w_issue<UT, RING_AG>(w3, ks_ptr(RES + 7), voff);
+    RSTAMP(1);
+#pragma unroll
+    for (int i = 0; i < RES; ++i) kstep(wr[i], i, i + 1 < RES ? i + 1 : RES + 4, resident);
+    RSTAMP(2);
+#pragma unroll 1
+    for (int ks = RES + 4; ks < KS; ks += 4) {
+      // refills: four streamed k-steps ahead, wrapping to the next step's first streamed ones
+      const int nx = ks + 4 < KS ? ks + 4 : RES;
+      kstep(w0, ks, ks + 1, steady);
+      w_issue<UT, RING_AG>(w0, ks_ptr(nx), voff);
+      kstep(w1, ks + 1, ks + 2, steady);
+      w_issue<UT, RING_AG>(w1, ks_ptr(nx + 1), voff);
+      kstep(w2, ks + 2, ks + 3, steady);
+      w_issue<UT, RING_AG>(w2, ks_ptr(nx + 2), voff);
+      kstep(w3, ks + 3, ks + 4 < KS ? ks + 4 : RES, steady);
+      w_issue<UT, RING_AG>(w3, ks_ptr(nx + 3), voff);
+    }
+    RSTAMP(3);
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) dh[jl] = acc[jl];
+    // the batch of step t landed before the fifth k-step's ring loads did; everything younger is the 4 * UT ring loads
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * UT) : "memory");
+    take_over(t);
+    issue_batch(t >= 1 ? t - 1 : 0);
+    RSTAMP(4);
+    wg_barrier();                                 // every wave has read the last fragments of dA_{t+1}
+    RSTAMP(5);
+    cell_bwd(t);
+#pragma unroll
+    for (int jl = 0; jl < JPW; ++jl) cvt[jl] = cvp[jl];
+  }
+  // keep the wrapped-around ring loads' registers live until they have landed
+  w_wait<0, UT, RING_AG>(w0);
+  w_wait<0, UT, RING_AG>(w1);
+  w_wait<0, UT, RING_AG>(w2);
+  w_wait<0, UT, RING_AG>(w3);
+
+#pragma unroll
+  for (int jl = 0; jl < JPW; ++jl) {
+    const int jt = wave * JPW + jl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = dbs[jl][q];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (g == 0) dbpart[(long)bt * (4 * H) + q * H + jt * 16 + r] = s;
+    }
+  }
+#ifdef VTS_RB_STAMP
+  __syncthreads();
+  if (tid == 0)
+    for (int i = 0; i < 8; ++i) dbpart[(long)bt * (4 * H) + i] = (float)rstamp[i] / (float)(T - 1);
+#endif
+#undef RSTAMP
+}
+
 template <int H, bool PL>
 int run_fwd3(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp, int B,
              int T, gp::SeqPlanes hp, hipStream_t stream) {
@@ -559,6 +867,23 @@ int run_bwd3(float* G, const float* cseq, const float* dhseq, const float* dhlas
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   hipLaunchKernelGGL((pack_whh3_kernel<H, true>), dim3(vts_cdiv(H * H, 256)), dim3(256), 0, stream, W_hh, img);
   VTS_CHECK_LAUNCH("pack_whh3_bwd");
+  if constexpr (H == 256) {
+    if (g_staged_bwd.load(std::memory_order_relaxed)) {
+      constexpr size_t LDS = R::LDS_B / 2 + (size_t)C::NW * 6 * C::JPW * 1024;
+      static vts_lds_mask done_dh{0}, done_nodh{0};
+      if (dhseq != nullptr) {
+        if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_bwd_staged_kernel<H, PL, true>), LDS, &done_dh, "lstm_rec3_bwd_staged")) return rc;
+        hipLaunchKernelGGL((lstm_rec3_bwd_staged_kernel<H, PL, true>), dim3((B + 15) / 16), dim3(C::NW * 64), LDS, stream, G,
+                           cseq, dhseq, dhlast, dclast, dbpart, img, B, T, dgp);
+      } else {
+        if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_bwd_staged_kernel<H, PL, false>), LDS, &done_nodh, "lstm_rec3_bwd_staged")) return rc;
+        hipLaunchKernelGGL((lstm_rec3_bwd_staged_kernel<H, PL, false>), dim3((B + 15) / 16), dim3(C::NW * 64), LDS, stream, G,
+                           cseq, dhseq, dhlast, dclast, dbpart, img, B, T, dgp);
+      }
+      VTS_CHECK_LAUNCH("lstm_rec3_bwd_staged");
+      return VTS_OK;
+    }
+  }
   static vts_lds_mask lds_done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3_bwd_kernel<H, PL>), R::LDS_B, &lds_done, "lstm_rec3_bwd")) return rc;
   hipLaunchKernelGGL((lstm_rec3_bwd_kernel<H, PL>), dim3((B + 15) / 16), dim3(C::NW * 64), R::LDS_B, stream, G, cseq, dhseq,
@@ -568,6 +893,8 @@ int run_bwd3(float* G, const float* cseq, const float* dhseq, const float* dhlas
 }
 
 }  // namespace
+
+void vts_lstm_rec3_set_staged_bwd(int on) { g_staged_bwd.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool vts_lstm_rec3_supported(int H) { return H == 64 || H == 128 || H == 256; }
 

@@ -54,6 +54,7 @@ int vts_attn_dropout_add(const float* residual, const float* x, const unsigned c
 int vts_attn_dropout_mask(unsigned long long seed, float drop_p, unsigned char* keep, long n, hipStream_t st);
 bool vts_lstm_hidden_supported(int H);
 bool vts_lstm_rec3_supported(int H);
+void vts_lstm_rec3_set_staged_bwd(int on);
 bool vts_lstm_rec3c_usable(int B, int T, int H);
 bool vts_planes_usable(long B, long T, long H);
 int vts_planes_fpad(long F);
@@ -302,6 +303,7 @@ int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_las
 
 static std::atomic<int> g_cluster_bwd{[] { const char* e = getenv("VTS_LSTM_CLUSTER_BWD"); return (e && e[0] == '1') ? 1 : 0; }()};
 void vts_debug_set_cluster_bwd(int on) { g_cluster_bwd.store(on ? 1 : 0); }
+void vts_debug_set_staged_bwd(int on) { vts_lstm_rec3_set_staged_bwd(on); }
 
 static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
                               const float* dc_last, const float* w_hh, float* db_ih, float* db_hh, int accumulate,
