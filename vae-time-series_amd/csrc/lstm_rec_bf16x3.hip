@@ -565,6 +565,7 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
   constexpr int KS = R::KS_B;
   constexpr int NB = 4 * JPW + JPW + (DH ? JPW : 0);   // loads per batch: gate tiles, cells, dh
   constexpr bool RING_AG = false;              // (true: the allocator spills and writes into ring registers in flight)
+  constexpr int PRE = JPW - 1;                 // hidden tiles whose coefficients are worked out inside the product
   constexpr int RES = 4;                       // k-steps of the image resident in registers
   static_assert(KS % 4 == 0 && KS >= RES + 8, "ring of four k-steps, batch retired by the fifth streamed one");
   static_assert(3 * UT + NB <= 63, "vmcnt is a six-bit counter");
@@ -627,10 +628,22 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
     }
   };
 
-  f32x4 gn[JPW * 4], dn[JPW], cvt[JPW], cvp[JPW];
+  // What the cell phase of a step needs of its saved tensors does not depend on dh, so it is worked out ahead, inside
+  // the product that computes dh (where the VALU idles under the W_hh stream): per element
+  //   kA = o (1 - tanh(c_t)^2)        dc_total = dc + dh kA
+  //   kO = tanh(c_t) o (1 - o)        dA_o = dh kO
+  //   kI = g i (1 - i)                dA_i = dc_total kI
+  //   kF = c_{t-1} f (1 - f)          dA_f = dc_total kF
+  //   kG = i (1 - g^2)                dA_g = dc_total kG
+  //   kf = f                          dc   = dc_total kf
+  // and tanh(c_{t-1}) is kept for the step after (tcn).
+  f32x4 kA[JPW], kO[JPW], kI[JPW], kF[JPW], kG[JPW], kf[JPW], tcn[JPW];
 #pragma unroll
-  for (int jl = 0; jl < JPW; ++jl)
-    cvt[jl] = ld_stream(cseq + ((long)(bt * T + T - 1) * C::JT + wave * JPW + jl) * 256 + lane * 4);
+  for (int jl = 0; jl < JPW; ++jl) {
+    const f32x4 c = ld_stream(cseq + ((long)(bt * T + T - 1) * C::JT + wave * JPW + jl) * 256 + lane * 4);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) tcn[jl][reg] = fast_tanh(c[reg]);
+  }
 
   u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
 #pragma unroll
@@ -649,17 +662,35 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
   issue_batch(T - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // staged gates -> registers, second register set -> first
-  auto take_over = [&](int t) {
+  // hidden tile jl of the staged batch of step t -> the coefficients above
+  auto premath = [&](int jl, int t) {
+    asm volatile("" ::: "memory");     // the staging reads stay behind the wait that proved the batch landed
+    const unsigned char* sj = stg + lane * 16;
+    const f32x4 gi = *reinterpret_cast<const f32x4*>(sj + (jl * 4 + 0) * 1024);
+    const f32x4 gf = *reinterpret_cast<const f32x4*>(sj + (jl * 4 + 1) * 1024);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(sj + (jl * 4 + 2) * 1024);
+    const f32x4 go = *reinterpret_cast<const f32x4*>(sj + (jl * 4 + 3) * 1024);
+    f32x4 cp = *reinterpret_cast<const f32x4*>(sj + (4 * JPW + jl) * 1024);
+    if (t < 1) cp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4 * JPW; ++i) gn[i] = *reinterpret_cast<const f32x4*>(stg + i * 1024 + lane * 16);
-#pragma unroll
-    for (int jl = 0; jl < JPW; ++jl) {
-      cvp[jl] = *reinterpret_cast<const f32x4*>(stg + (4 * JPW + jl) * 1024 + lane * 16);
-      if (t < 1) cvp[jl] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dn[jl] = DH ? *reinterpret_cast<const f32x4*>(stg + (5 * JPW + jl) * 1024 + lane * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int reg = 0; reg < 4; ++reg) {
+      const float tc = tcn[jl][reg];
+      kA[jl][reg] = go[reg] * (1.f - tc * tc);
+      kO[jl][reg] = tc * (go[reg] * (1.f - go[reg]));
+      kI[jl][reg] = gg[reg] * (gi[reg] * (1.f - gi[reg]));
+      kF[jl][reg] = cp[reg] * (gf[reg] * (1.f - gf[reg]));
+      kG[jl][reg] = gi[reg] * (1.f - gg[reg] * gg[reg]);
+      kf[jl][reg] = gf[reg];
+      tcn[jl][reg] = fast_tanh(cp[reg]);
     }
-    // the copies are complete (and the staging area free) before the next batch may overwrite their sources
+  };
+  // dh_t of the staged batch joins the recurrent part; after it the staging area is free for the next batch
+  auto take_dh = [&] {
+    asm volatile("" ::: "memory");
+    if (DH) {
+#pragma unroll
+      for (int jl = 0; jl < JPW; ++jl) dh[jl] += *reinterpret_cast<const f32x4*>(stg + (5 * JPW + jl) * 1024 + lane * 16);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -667,32 +698,19 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
   auto cell_bwd = [&](int t) {
     float* Gt = G + ((long)(bt * T + t) * (4 * C::JT)) * 256 + lane * 4;
     char* dg_t = PL ? dgp.base + dgp.tile(bt, t, 2 * wave * JPW, 0) + pl_off : nullptr;
-    u32x4 pf[4];
-    auto put_planes = [&](int jl) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)     // tile (k-step 2 * jl + (i >> 1), plane i & 1) of the wave's column blocks
-        __builtin_nontemporal_store(pf[i], reinterpret_cast<u32x4*>(dg_t + (4 * jl + i) * gp::TILE_B));
-    };
 #pragma unroll
     for (int jl = 0; jl < JPW; ++jl) {
       const int jt = wave * JPW + jl;
-      const f32x4 gi = gn[jl * 4 + 0], gf = gn[jl * 4 + 1], gg = gn[jl * 4 + 2], go = gn[jl * 4 + 3];
-      const f32x4 ct = cvt[jl], cp = cvp[jl];
-      const f32x4 dht = dh[jl] + dn[jl];
+      const f32x4 dht = dh[jl];
       f32x4 dai, daf, dag, dao;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const float tc = fast_tanh(ct[reg]);
-        const float d_o = dht[reg] * tc;
-        const float dcc = dc[jl][reg] + dht[reg] * go[reg] * (1.f - tc * tc);
-        const float d_i = dcc * gg[reg];
-        const float d_g = dcc * gi[reg];
-        const float d_f = dcc * cp[reg];
-        dc[jl][reg] = dcc * gf[reg];
-        dai[reg] = d_i * gi[reg] * (1.f - gi[reg]);
-        daf[reg] = d_f * gf[reg] * (1.f - gf[reg]);
-        dag[reg] = d_g * (1.f - gg[reg] * gg[reg]);
-        dao[reg] = d_o * go[reg] * (1.f - go[reg]);
+        const float dcc = dc[jl][reg] + dht[reg] * kA[jl][reg];
+        dc[jl][reg] = dcc * kf[jl][reg];
+        dai[reg] = dcc * kI[jl][reg];
+        daf[reg] = dcc * kF[jl][reg];
+        dag[reg] = dcc * kG[jl][reg];
+        dao[reg] = dht[reg] * kO[jl][reg];
         uint2 hi, lo;
         split4(dai[reg], daf[reg], dag[reg], dao[reg], hi, lo);
         const int row = 4 * g + reg;
@@ -713,17 +731,22 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
       } else {
         // The plane tiles of this hidden tile (k-steps 2 * jt and 2 * jt + 1, both planes) are the wave's own LDS
         // writes read back in fragment order - LDS operations of a wave execute in order, no barrier needed - and go
-        // out one hidden tile later, while the VALU works on the next one and the W_hh stream pauses anyway.
+        // out at once, while the W_hh stream pauses anyway.
         // (Stored from inside the k-steps, as the product reads the fragments, they cost the stream a tenth of
         // its rate.)
-        if (jl > 0) put_planes(jl - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          pf[i] = *reinterpret_cast<const u32x4*>(da_s + (i & 1) * PLANE + r * ROWB + (((4 * (2 * jt + (i >> 1)) + g) ^ r) << 4));
+        for (int hf = 0; hf < 2; ++hf) {     // one k-step (two tiles) at a time: eight registers, not sixteen
+          u32x4 pf[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            pf[p] = *reinterpret_cast<const u32x4*>(da_s + p * PLANE + r * ROWB + (((4 * (2 * jt + hf) + g) ^ r) << 4));
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            __builtin_nontemporal_store(pf[p], reinterpret_cast<u32x4*>(dg_t + (4 * jl + 2 * hf + p) * gp::TILE_B));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (PL) put_planes(JPW - 1);
   };
 
   // (the last step's "next batch" is step 0 once more: an unconditional issue keeps the count of loads in the
@@ -736,11 +759,11 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
 #else
 #define RSTAMP(i)
 #endif
-  take_over(T - 1);
+#pragma unroll
+  for (int jl = 0; jl < JPW; ++jl) premath(jl, T - 1);
+  take_dh();
   issue_batch(T >= 2 ? T - 2 : 0);
   cell_bwd(T - 1);
-#pragma unroll
-  for (int jl = 0; jl < JPW; ++jl) cvt[jl] = cvp[jl];
   for (int t = T - 2; t >= 0; --t) {
     RSTAMP(6);                                    // (cell backward of the step before)
     wg_barrier();                                 // dA_{t+1} is complete
@@ -751,11 +774,12 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
     auto lds_a = [&](int plane, int ks) {
       return *reinterpret_cast<const u32x4*>(da_s + plane * PLANE + r * ROWB + (((4 * ks + g) ^ r) << 4));
     };
-    u32x4 ah = lds_a(0, RES), al = lds_a(1, RES);
-    // one k-step; kn = the k-step that runs next (its A fragments are fetched now); allowed < 0: a resident
-    // buffer, nothing to wait for
+    // one k-step (kn, the k-step that runs next, is not used: the A fragments are fetched just in time - their
+    // LDS latency hides behind the wait for the ring buffer, and a prefetched pair would cost eight registers this
+    // kernel does not have); allowed < 0: a resident buffer, nothing to wait for
     auto kstep = [&](u32x4 (&w)[UT], int ks, int kn, auto allowed) {
-      const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);
+      (void)kn;
+      const u32x4 ah = lds_a(0, ks), al = lds_a(1, ks);
       if constexpr (decltype(allowed)::value >= 0) w_wait<decltype(allowed)::value, UT, RING_AG>(w);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -768,8 +792,6 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
       for (int jl = 0; jl < JPW; ++jl)
         acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(w[jl]), acc[jl], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      ah = nh;
-      al = nl;
     };
     // On entry the queue holds, oldest first: w0 w1 w2 w3 (k-steps RES..RES+3, issued at the end of the previous
     // product), then the batch of step t (NB loads).  Each streamed k-step waits for its buffer, then refills it
@@ -791,9 +813,8 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
 #pragma unroll
     for (int i = 0; i < RES; ++i) kstep(wr[i], i, i + 1 < RES ? i + 1 : RES + 4, resident);
     RSTAMP(2);
-#pragma unroll 1
-    for (int ks = RES + 4; ks < KS; ks += 4) {
-      // refills: four streamed k-steps ahead, wrapping to the next step's first streamed ones
+    // four streamed k-steps ks..ks+3; refills four streamed k-steps ahead, wrapping to the next step's first ones
+    auto group = [&](int ks) {
       const int nx = ks + 4 < KS ? ks + 4 : RES;
       kstep(w0, ks, ks + 1, steady);
       w_issue<UT, RING_AG>(w0, ks_ptr(nx), voff);
@@ -803,20 +824,31 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_staged_kerne
       w_issue<UT, RING_AG>(w2, ks_ptr(nx + 2), voff);
       kstep(w3, ks + 3, ks + 4 < KS ? ks + 4 : RES, steady);
       w_issue<UT, RING_AG>(w3, ks_ptr(nx + 3), voff);
+    };
+    // the first group's first wait retires the batch of step t: each of the next JPW groups is followed by the
+    // coefficient arithmetic of one hidden tile, which the VALU does while the matrix pipe and the ring are busy
+    // (PRE of the JPW tiles: the registers do not hold the coefficients of all of them beside the ring and the
+    // resident part of the image; the others follow when the product is over)
+    static_assert(RES + 4 + 4 * PRE <= KS, "a group of k-steps per hidden tile");
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+      group(RES + 4 + 4 * i);
+      premath(i, t);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll 1
+    for (int ks = RES + 4 + 4 * PRE; ks < KS; ks += 4) group(ks);
     RSTAMP(3);
 #pragma unroll
     for (int jl = 0; jl < JPW; ++jl) dh[jl] = acc[jl];
-    // the batch of step t landed before the fifth k-step's ring loads did; everything younger is the 4 * UT ring loads
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * UT) : "memory");
-    take_over(t);
+#pragma unroll
+    for (int i = PRE; i < JPW; ++i) premath(i, t);
+    take_dh();
     issue_batch(t >= 1 ? t - 1 : 0);
     RSTAMP(4);
     wg_barrier();                                 // every wave has read the last fragments of dA_{t+1}
     RSTAMP(5);
     cell_bwd(t);
-#pragma unroll
-    for (int jl = 0; jl < JPW; ++jl) cvt[jl] = cvp[jl];
   }
   // keep the wrapped-around ring loads' registers live until they have landed
   w_wait<0, UT, RING_AG>(w0);
