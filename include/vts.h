@@ -324,6 +324,37 @@ int vts_elbo_sums(int family, const float* recon, const float* y, const float* m
 int vts_elbo_from_sums(int family, const float* sums, const float* pi, float beta, float n_ranks, float* state,
                        int64_t fs, int64_t L, vts_stream_t stream);
 
+/* ---- Fused head / decoder chains -------------------------------------------------------------------------
+ * gpd-lstm-DE.py:29-33,45-47 ; mixture-vae-DE.py:62-69,81-83 ; gaussian-lstm-DE.py:30-31,43-45.
+ * n_trunk (0..3) Linear + activation layers, then n_heads (1..8) Linear heads of equal width that all read the last
+ * trunk output (the chain input when there is no trunk): the encoder's relu(fc1) -> dropout(relu(fc2)) ->
+ * {mean, logvar, exp(scale), clamp(shape)} and the decoders' relu(fc1) -> dropout(relu(fc2)) -> out are each one such
+ * chain.  One launch forward, two backward, fp32 arithmetic in every mode; same results as the layers run one by
+ * one with vts_linear_fwd / vts_linear_bwd up to the order of fp32 sums.
+ * Widths: multiples of 4, at most 512 (the heads together too); several heads need a width that is a multiple of
+ * 16.  trunk_act: VTS_ACT_NONE / RELU / RELU_DROPOUT, head_act: NONE / RELU / EXP / CLAMP_MIN.
+ * w, b: n_trunk + n_heads pointers (trunk first), w[i] = [N_i, K_i] row-major as nn.Linear keeps it; keep: n_trunk
+ * pointers to [B, trunk_dim] 0/1 masks for the RELU_DROPOUT layers (NULL entries or NULL = eval mode), kept values
+ * scaled by keep_scale; trunk_out[i] [B, trunk_dim[i]] and head_out[h] [B, head_dim] receive the post-activation
+ * outputs (the backward pass reads them); head_aux[h] [B, head_dim] is needed for CLAMP_MIN heads only. */
+typedef struct vts_mlp_chain {
+  int32_t n_trunk, n_heads, in_dim, head_dim;
+  int32_t trunk_dim[3], trunk_act[3];
+  int32_t head_act[8];
+  float keep_scale;
+} vts_mlp_chain;
+int vts_mlp_chain_supported(const vts_mlp_chain* chain, int64_t B);
+int vts_mlp_chain_fwd(const vts_mlp_chain* chain, const float* x, int64_t ldx, int64_t B, const float* const* w,
+                      const float* const* b, const float* const* keep, float* const* trunk_out, float* const* head_out,
+                      float* const* head_aux, vts_stream_t stream);
+size_t vts_mlp_chain_bwd_workspace_bytes(const vts_mlp_chain* chain, int64_t B);
+/* d_head[h]: gradient w.r.t. head output h (NULL entry = zero); dx [B, in_dim] with row stride lddx (NULL = not
+ * needed); dw[i], db[i] as w, b (db or its entries may be NULL).  Everything is overwritten, nothing accumulated. */
+int vts_mlp_chain_bwd(const vts_mlp_chain* chain, const float* x, int64_t ldx, int64_t B, const float* const* w,
+                      const float* const* keep, float* const* trunk_out, float* const* head_out,
+                      float* const* head_aux, const float* const* d_head, float* dx, int64_t lddx, float* const* dw,
+                      float* const* db, void* workspace, size_t workspace_bytes, vts_stream_t stream);
+
 /* ---- Transformer encoder layer pieces: nn.TransformerEncoderLayer(d_model, nhead, dropout=0.2) ----
  * mixture-vae-transformer.py:39-40,49.  A layer is: packed in-projection (vts_linear_fwd) -> vts_mha_fwd ->
  * out-projection -> vts_dropout_add_fwd -> vts_layernorm_fwd -> vts_linear_relu_dropout_fwd -> vts_linear_fwd

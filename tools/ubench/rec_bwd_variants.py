@@ -46,7 +46,7 @@ def variant(n):
     return head + s + tail
 
 
-objs = "vts_api.o gemm_f32.o lstm_rec_f32.o lstm_rec_cluster.o lstm_planes.o elementwise.o attention.o ffn_fused.o windows.o mixture3.o".split()
+objs = "vts_api.o gemm_f32.o lstm_rec_f32.o lstm_rec_cluster.o lstm_planes.o mlp_chain.o elementwise.o attention.o ffn_fused.o windows.o mixture3.o".split()
 os.makedirs("/tmp/recx", exist_ok=True)
 for n in (sys.argv[1:] or "1 2 3 4 5".split()):
     p = os.path.join(CSRC, "_recx%s.hip" % n)

@@ -53,6 +53,16 @@ int vts_attn_dropout_add(const float* residual, const float* x, const unsigned c
                          unsigned long long seed, float* out, long n, hipStream_t st);
 int vts_attn_dropout_mask(unsigned long long seed, float drop_p, unsigned char* keep, long n, hipStream_t st);
 bool vts_lstm_hidden_supported(int H);
+struct vts_mlp_chain_desc;
+int vts_mlp_chain_supported_impl(const vts_mlp_chain_desc* d, long B);
+int vts_mlp_chain_fwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx, long B, const float* const* w,
+                           const float* const* b, const float* const* keep, float* const* trunk_out,
+                           float* const* head_out, float* const* head_aux, hipStream_t st);
+size_t vts_mlp_chain_bwd_workspace_bytes_impl(const vts_mlp_chain_desc* d, long B);
+int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx, long B, const float* const* w,
+                           const float* const* keep, float* const* trunk_out, float* const* head_out,
+                           float* const* head_aux, const float* const* d_head, float* dx, long lddx, float* const* dw,
+                           float* const* db, void* workspace, size_t workspace_bytes, hipStream_t st);
 bool vts_lstm_rec3_supported(int H);
 void vts_lstm_rec3_set_staged_bwd(int on);
 bool vts_lstm_rec3c_usable(int B, int T, int H);
@@ -988,6 +998,31 @@ int vts_adam_step_counted(float* param, const float* grad, float* exp_avg, float
 int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream) {
   VTS_REQUIRE(in && scalar && out && n > 0, "scale: bad arguments");
   return vts_ew_scale(in, scalar, out, n, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- fused head / decoder chains (mlp_chain.hip); vts_mlp_chain and vts_mlp_chain_desc have the same layout
+int vts_mlp_chain_supported(const vts_mlp_chain* chain, int64_t B) {
+  return vts_mlp_chain_supported_impl(reinterpret_cast<const vts_mlp_chain_desc*>(chain), (long)B);
+}
+int vts_mlp_chain_fwd(const vts_mlp_chain* chain, const float* x, int64_t ldx, int64_t B, const float* const* w,
+                      const float* const* b, const float* const* keep, float* const* trunk_out, float* const* head_out,
+                      float* const* head_aux, vts_stream_t stream) {
+  VTS_REQUIRE(chain != nullptr && w != nullptr, "vts_mlp_chain_fwd: missing argument");
+  return vts_mlp_chain_fwd_impl(reinterpret_cast<const vts_mlp_chain_desc*>(chain), x, (long)ldx, (long)B, w, b, keep,
+                                trunk_out, head_out, head_aux, (hipStream_t)stream);
+}
+size_t vts_mlp_chain_bwd_workspace_bytes(const vts_mlp_chain* chain, int64_t B) {
+  return chain ? vts_mlp_chain_bwd_workspace_bytes_impl(reinterpret_cast<const vts_mlp_chain_desc*>(chain), (long)B) : 0;
+}
+int vts_mlp_chain_bwd(const vts_mlp_chain* chain, const float* x, int64_t ldx, int64_t B, const float* const* w,
+                      const float* const* keep, float* const* trunk_out, float* const* head_out,
+                      float* const* head_aux, const float* const* d_head, float* dx, int64_t lddx, float* const* dw,
+                      float* const* db, void* workspace, size_t workspace_bytes, vts_stream_t stream) {
+  VTS_REQUIRE(chain != nullptr && w != nullptr, "vts_mlp_chain_bwd: missing argument");
+  VTS_REQUIRE(dx == nullptr || lddx >= chain->in_dim, "vts_mlp_chain_bwd: lddx too small");
+  return vts_mlp_chain_bwd_impl(reinterpret_cast<const vts_mlp_chain_desc*>(chain), x, (long)ldx, (long)B, w, keep,
+                                trunk_out, head_out, head_aux, d_head, dx, (long)lddx, dw, db, workspace, workspace_bytes,
+                                (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -5,7 +5,7 @@ sites.  All arithmetic runs in the HIP library; torch supplies device memory, st
 torch.distributed.  Importing works without a GPU; calling any op without one raises.
 """
 from . import _lib
-from .functional import get_mode, set_mode, set_loss_reduction
+from .functional import get_mode, set_mode, set_loss_reduction, set_fused_chains, mlp_chain
 from .functional import (gaussian_elbo, gpd_elbo, layer_norm, linear, lstm, mixture_elbo,
                          reparameterize_gaussian, reparameterize_gpd, reparameterize_mixture,
                          mixture_split_elbo, multi_head_attention, dropout_add, dropout_mask,

@@ -22,6 +22,21 @@ FAMILY = {"gaussian": GAUSSIAN, "gpd": GPD, "mixture": MIXTURE}
 
 _i64, _f32, _int, _ptr, _sz, _u64 = C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_uint64
 
+class MlpChain(C.Structure):
+    """vts_mlp_chain of include/vts.h."""
+    _fields_ = [("n_trunk", C.c_int32), ("n_heads", C.c_int32), ("in_dim", C.c_int32), ("head_dim", C.c_int32),
+                ("trunk_dim", C.c_int32 * 3), ("trunk_act", C.c_int32 * 3), ("head_act", C.c_int32 * 8),
+                ("keep_scale", C.c_float)]
+
+
+def ptr_array(tensors):
+    """A host array of device pointers (None entries = NULL) for the `const float* const*` arguments."""
+    arr = (C.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
 # name -> (restype, argtypes); mirrors include/vts.h one to one
 SIGNATURES = {
     "vts_version": (C.c_char_p, []),
@@ -61,6 +76,10 @@ SIGNATURES = {
     "vts_linear_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vts_linear_bwd": (_int, [_ptr, _ptr, _ptr, _int, _f32, _ptr, _i64, _ptr, _ptr, _i64, _int, _ptr, _ptr, _int,
                               _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
+    "vts_mlp_chain_supported": (_int, [_ptr, _i64]),
+    "vts_mlp_chain_fwd": (_int, [_ptr, _ptr, _i64, _i64] + [_ptr] * 6 + [_ptr]),
+    "vts_mlp_chain_bwd_workspace_bytes": (_sz, [_ptr, _i64]),
+    "vts_mlp_chain_bwd": (_int, [_ptr, _ptr, _i64, _i64] + [_ptr] * 6 + [_ptr, _i64, _ptr, _ptr, _ptr, _sz, _ptr]),
     "vts_layernorm_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr]),
     "vts_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "vts_layernorm_bwd": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _int, _ptr, _sz,

@@ -9,6 +9,9 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import ctypes as C
+import os
+
 import torch
 
 from . import _lib as L
@@ -16,6 +19,19 @@ from . import _lib as L
 DROP_P = 0.3
 MODES = {"f32": 0, "bf16x3": 1}
 _MODE = 0  # dtype_mode of the C ABI passed to the LSTM GEMM stages
+# the encoder heads and the decoders as fused chains (vts_mlp_chain_*); VTS_FUSED_CHAINS=0 runs them layer by layer
+_FUSED_CHAINS = os.environ.get("VTS_FUSED_CHAINS", "1")[:1] != "0"
+
+
+# test aid: when a dict, mlp_chain stores the trunk outputs of every chain it runs under the names it was given
+CHAIN_TAPS = None
+
+
+def set_fused_chains(on: bool) -> None:
+    """Run the encoder heads and the decoders as fused chains (default) or layer by layer."""
+    global _FUSED_CHAINS
+    _FUSED_CHAINS = bool(on)
+
 
 
 def set_mode(name: str) -> None:
@@ -342,6 +358,106 @@ def feed_forward(x, w1, b1, w2, b2, keep=None, drop_p: float = 0.0, seed: int = 
     """linear2(dropout(relu(linear1(x)))): the feed-forward block of an encoder layer.  ``keep`` is a
     float 0/1 mask [M, dim_feedforward]; else ``seed`` != 0 draws it with the counter hash; else eval."""
     return _FeedForward.apply(x, w1, b1, w2, b2, keep, drop_p, seed)
+
+
+# ----------------------------------------------------------------- fused head / decoder chains
+class _MlpChain(torch.autograd.Function):
+    """Trunk layers + heads as one autograd node over vts_mlp_chain_fwd / vts_mlp_chain_bwd.
+    Arguments after the fixed ones: w_0, b_0, w_1, b_1, ... (trunk layers, then heads)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, keeps, *params):
+        _need_gpu(x)
+        lib = L.load()
+        trunk_acts, head_acts, scale, names = cfg
+        nt, nh = len(trunk_acts), len(head_acts)
+        if x.dim() != 2 or x.stride(1) != 1:
+            x = x.reshape(-1, x.shape[-1]).contiguous()
+        B, K = x.shape
+        ws = [p.contiguous() for p in params[0::2]]
+        bs = [None if p is None else p.contiguous() for p in params[1::2]]
+        keeps = [None if k is None else _c(k) for k in keeps]
+        d = L.MlpChain()
+        d.n_trunk, d.n_heads, d.in_dim, d.head_dim = nt, nh, K, ws[nt].shape[0]
+        for i in range(nt):
+            d.trunk_dim[i] = ws[i].shape[0]
+            # a dropout layer without a mask is a plain relu (eval mode)
+            d.trunk_act[i] = L.ACT_RELU if (trunk_acts[i] == L.ACT_RELU_DROPOUT and keeps[i] is None) else trunk_acts[i]
+        for i in range(nh):
+            d.head_act[i] = head_acts[i]
+        d.keep_scale = scale
+        dev = x.device
+        touts = [torch.empty(B, ws[i].shape[0], device=dev, dtype=torch.float32) for i in range(nt)]
+        houts = [torch.empty(B, d.head_dim, device=dev, dtype=torch.float32) for _ in range(nh)]
+        hauxs = [torch.empty(B, d.head_dim, device=dev, dtype=torch.float32) if head_acts[i] == L.ACT_CLAMP_MIN else None
+                 for i in range(nh)]
+        L.check(L.timer.call(f"mlp_chain_fwd {B}x{K}", lib.vts_mlp_chain_fwd, C.byref(d), L.ptr(x), x.stride(0), B,
+                             L.ptr_array(ws), L.ptr_array(bs), L.ptr_array(keeps), L.ptr_array(touts),
+                             L.ptr_array(houts), L.ptr_array(hauxs), L.stream()), "vts_mlp_chain_fwd")
+        if CHAIN_TAPS is not None:
+            for name, t in zip(names, touts):
+                CHAIN_TAPS[name] = t.detach()
+        ctx.desc = d
+        ctx.counts = (nt, nh, [b is not None for b in bs])
+        ctx.save_for_backward(x, *ws, *[k for k in keeps if k is not None], *touts, *houts,
+                              *[a for a in hauxs if a is not None])
+        ctx.keep_at = [k is not None for k in keeps]
+        ctx.aux_at = [a is not None for a in hauxs]
+        return tuple(houts)
+
+    @staticmethod
+    def backward(ctx, *d_heads):
+        lib = L.load()
+        nt, nh, has_bias = ctx.counts
+        saved = list(ctx.saved_tensors)
+        x = saved.pop(0)
+        ws = [saved.pop(0) for _ in range(nt + nh)]
+        keeps = [saved.pop(0) if flag else None for flag in ctx.keep_at]
+        touts = [saved.pop(0) for _ in range(nt)]
+        houts = [saved.pop(0) for _ in range(nh)]
+        hauxs = [saved.pop(0) if flag else None for flag in ctx.aux_at]
+        B, K = x.shape
+        dev = x.device
+        d = ctx.desc
+        d_heads = [None if g is None else g.contiguous() for g in d_heads]
+        dx = torch.empty(B, K, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty(w.shape[0], device=dev, dtype=torch.float32) if hb else None for w, hb in zip(ws, has_bias)]
+        ws_bytes = lib.vts_mlp_chain_bwd_workspace_bytes(C.byref(d), B)
+        wsp = L.workspace(ws_bytes, dev)
+        L.check(L.timer.call(f"mlp_chain_bwd {B}x{K}", lib.vts_mlp_chain_bwd, C.byref(d), L.ptr(x), x.stride(0), B,
+                             L.ptr_array(ws), L.ptr_array(keeps), L.ptr_array(touts), L.ptr_array(houts),
+                             L.ptr_array(hauxs), L.ptr_array(d_heads), L.ptr(dx), K, L.ptr_array(dws), L.ptr_array(dbs),
+                             L.wptr(wsp), ws_bytes, L.stream()), "vts_mlp_chain_bwd")
+        grads = []
+        for dw, db in zip(dws, dbs):
+            grads += [dw, db]
+        return (dx, None, None, *grads)
+
+
+def mlp_chain_usable(x, trunk, heads) -> bool:
+    """Whether vts_mlp_chain_* takes this chain (widths and alignment; see include/vts.h)."""
+    if not _FUSED_CHAINS or x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        return False
+    dims = [x.shape[1]] + [w.shape[0] for w, _, _ in trunk]
+    if any(v % 4 or v > 512 for v in dims) or len(trunk) > 3 or not 1 <= len(heads) <= 8:
+        return False
+    hd = heads[0][0].shape[0]
+    if any(w.shape[0] != hd for w, _, _ in heads) or hd * len(heads) > 512 or (len(heads) > 1 and hd % 16):
+        return False
+    return all(a in (L.ACT_NONE, L.ACT_RELU, L.ACT_RELU_DROPOUT) for _, _, a in trunk)
+
+
+def mlp_chain(x, trunk, heads, keeps=None, drop_p: float = DROP_P, names=None):
+    """Trunk layers [(weight, bias, act), ...] then heads [(weight, bias, act), ...] that all read the last trunk
+    output; returns the tuple of head outputs.  ``keeps``: one float 0/1 mask (or None) per trunk layer, used by the
+    ACT_RELU_DROPOUT ones (None there = eval mode).  ``names``: names of the trunk layers for CHAIN_TAPS."""
+    keeps = list(keeps) if keeps is not None else [None] * len(trunk)
+    params = []
+    for w, b, _ in list(trunk) + list(heads):
+        params += [w, b]
+    cfg = ([a for _, _, a in trunk], [a for _, _, a in heads], 1.0 / (1.0 - drop_p), tuple(names or ()))
+    return _MlpChain.apply(x, cfg, keeps, *params)
 
 
 # -------------------------------------------------------------------------------- LayerNorm

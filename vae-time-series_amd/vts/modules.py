@@ -101,6 +101,10 @@ class GaussianEncoder(nn.Module):
     def forward(self, x):
         _, (h_n, _) = self.lstm(x, need_output=False)
         h = h_n[-1]
+        heads = [(self.mean_layer.weight, self.mean_layer.bias, L.ACT_NONE),
+                 (self.logvar_layer.weight, self.logvar_layer.bias, L.ACT_NONE)]
+        if F.mlp_chain_usable(h, [], heads):
+            return F.mlp_chain(h, [], heads)
         return self.mean_layer(h), self.logvar_layer(h)
 
 
@@ -111,6 +115,10 @@ class GaussianDecoder(nn.Module):
         self.out = Linear(500, future_steps)
 
     def forward(self, z):
+        trunk = [(self.dense1.weight, self.dense1.bias, L.ACT_RELU)]
+        heads = [(self.out.weight, self.out.bias, L.ACT_NONE)]
+        if F.mlp_chain_usable(z, trunk, heads):
+            return F.mlp_chain(z, trunk, heads, names=("decoder.dense1",))[0]
         return self.out(self.dense1(z, act=L.ACT_RELU))
 
 
@@ -160,14 +168,27 @@ class DeepEncoder(nn.Module):
     def forward(self, x, noise: Noise = None):
         _, (h_n, _) = self.lstm(x, need_output=False)
         h = self.layer_norm(h_n[-1])
+        keep = _keep_mask(noise, "enc_keep", self.training, (h.shape[0], 64), h.device)
+        trunk = [(self.fc1.weight, self.fc1.bias, L.ACT_RELU), (self.fc2.weight, self.fc2.bias, L.ACT_RELU_DROPOUT)]
+        heads = self._heads()
+        if F.mlp_chain_usable(h, trunk, heads):
+            return F.mlp_chain(h, trunk, heads, [None, keep], names=("encoder.fc1", "encoder.fc2"))
         hidden = self.fc1(h, act=L.ACT_RELU)
-        keep = _keep_mask(noise, "enc_keep", self.training, (hidden.shape[0], 64), hidden.device)
         hidden = self.fc2(hidden, act=L.ACT_RELU_DROPOUT, keep=keep)
         scale = self.scale_layer_extreme(hidden, act=L.ACT_EXP)
         shape = self.shape_layer_extreme(hidden, act=L.ACT_CLAMP_MIN)
         if self.gaussian_heads:
             return self.mean_layer_normal(hidden), self.logvar_layer_normal(hidden), scale, shape
         return scale, shape
+
+    def _heads(self):
+        """(weight, bias, activation) of the heads in the order forward returns them."""
+        hs = []
+        if self.gaussian_heads:
+            hs += [(self.mean_layer_normal.weight, self.mean_layer_normal.bias, L.ACT_NONE),
+                   (self.logvar_layer_normal.weight, self.logvar_layer_normal.bias, L.ACT_NONE)]
+        return hs + [(self.scale_layer_extreme.weight, self.scale_layer_extreme.bias, L.ACT_EXP),
+                     (self.shape_layer_extreme.weight, self.shape_layer_extreme.bias, L.ACT_CLAMP_MIN)]
 
 
 class DeepDecoder(nn.Module):
@@ -178,8 +199,12 @@ class DeepDecoder(nn.Module):
         self.out = Linear(500, future_steps)
 
     def forward(self, z, noise: Noise = None):
-        z = self.fc1(z, act=L.ACT_RELU)
         keep = _keep_mask(noise, "dec_keep", self.training, (z.shape[0], 500), z.device)
+        trunk = [(self.fc1.weight, self.fc1.bias, L.ACT_RELU), (self.fc2.weight, self.fc2.bias, L.ACT_RELU_DROPOUT)]
+        heads = [(self.out.weight, self.out.bias, L.ACT_NONE)]
+        if F.mlp_chain_usable(z, trunk, heads):
+            return F.mlp_chain(z, trunk, heads, [None, keep], names=("decoder.fc1", "decoder.fc2"))[0]
+        z = self.fc1(z, act=L.ACT_RELU)
         z = self.fc2(z, act=L.ACT_RELU_DROPOUT, keep=keep)
         return self.out(z)
 
@@ -252,8 +277,12 @@ class ThreeComponentEncoder(DeepEncoder):
     def forward(self, x, noise: Noise = None):
         _, (h_n, _) = self.lstm(x, need_output=False)
         h = self.layer_norm(h_n[-1])
+        keep = _keep_mask(noise, "enc_keep", self.training, (h.shape[0], 64), h.device)
+        trunk = [(self.fc1.weight, self.fc1.bias, L.ACT_RELU), (self.fc2.weight, self.fc2.bias, L.ACT_RELU_DROPOUT)]
+        heads = self._heads() + [(self.logits_layer_zero.weight, self.logits_layer_zero.bias, L.ACT_NONE)]
+        if F.mlp_chain_usable(h, trunk, heads):
+            return F.mlp_chain(h, trunk, heads, [None, keep], names=("encoder.fc1", "encoder.fc2"))
         hidden = self.fc1(h, act=L.ACT_RELU)
-        keep = _keep_mask(noise, "enc_keep", self.training, (hidden.shape[0], 64), hidden.device)
         hidden = self.fc2(hidden, act=L.ACT_RELU_DROPOUT, keep=keep)
         return (self.mean_layer_normal(hidden), self.logvar_layer_normal(hidden),
                 self.scale_layer_extreme(hidden, act=L.ACT_EXP), self.shape_layer_extreme(hidden, act=L.ACT_CLAMP_MIN),
