@@ -213,14 +213,15 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, co
 }
 
 // ---- backward 2: weight and bias gradients of every matrix of the chain -----------------------------------------
-// One wave per 16 x 16 tile of some dW = dpre^T . input, contracted over all rows.
+// One workgroup per 16 x 16 tile of some dW = dpre^T . input, contracted over all rows: its four waves take every
+// fourth group of 16 rows (four groups in flight each) and their partial tiles are added up through LDS in a fixed
+// order.
 __global__ __launch_bounds__(256) void mlp_chain_bwd_dw_kernel(const Chain D, const ChainBwd R, const float* __restrict__ x,
                                                                long ldx, int B) {
+  __shared__ float red[3][64][5];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int nm = D.n_trunk + D.n_heads;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= R.tile0[nm]) return;
+  const int tile = blockIdx.x;
   int mi = 0;
   while (tile >= R.tile0[mi + 1]) ++mi;
   const bool head = mi >= D.n_trunk;
@@ -235,20 +236,41 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dw_kernel(const Chain D, co
   const int t = tile - R.tile0[mi];
   const int n0 = (t / ktiles) << 4, k0 = (t % ktiles) << 4;
   const int n = n0 + r, k = k0 + r;
-  const int nc = n < N ? n : N - 1, kc = k < K ? k : K - 1;
+  const float* dpc = dp + (n < N ? n : N - 1);
+  const float* srcc = src + (k < K ? k : K - 1);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  for (int row0 = 0; row0 < B; row0 += 16) {
-    f32x4 av, bv;
+  auto fetch = [&](int row0, f32x4& av, f32x4& bv) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const long row = row0 + 4 * q + e;
       const bool in = row < B;
-      av[e] = in ? dp[row * ldd + nc] : 0.f;
-      bv[e] = in ? src[row * lds_ + kc] : 0.f;
+      av[e] = in ? dpc[row * ldd] : 0.f;
+      bv[e] = in ? srcc[row * lds_] : 0.f;
     }
-    bsum += (av[0] + av[1]) + (av[2] + av[3]);
-    acc = mfma4(av, bv, acc);
+  };
+  for (int row0 = 16 * wave; row0 < B; row0 += 256) {
+    f32x4 av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch(row0 + 64 * u, av[u], bv[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bsum += (av[u][0] + av[u][1]) + (av[u][2] + av[u][3]);
+      acc = mfma4(av[u], bv[u], acc);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave - 1][lane][i] = acc[i];
+    red[wave - 1][lane][4] = bsum;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += red[w][lane][i];
+    bsum += red[w][lane][4];
   }
   float* dw = R.dw[mi];
 #pragma unroll
@@ -378,7 +400,7 @@ int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_bwd_dx_kernel), CHAIN_LDS, &lds_done, "mlp_chain_bwd_dx")) return rc;
   hipLaunchKernelGGL(mlp_chain_bwd_dx_kernel, dim3((unsigned)((B + TM - 1) / TM)), dim3(256), CHAIN_LDS, st, D, R, (int)B);
   VTS_CHECK_LAUNCH("mlp_chain_bwd_dx");
-  hipLaunchKernelGGL(mlp_chain_bwd_dw_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, D, R, x, ldx, (int)B);
+  hipLaunchKernelGGL(mlp_chain_bwd_dw_kernel, dim3((unsigned)tiles), dim3(256), 0, st, D, R, x, ldx, (int)B);
   VTS_CHECK_LAUNCH("mlp_chain_bwd_dw");
   return VTS_OK;
 }
