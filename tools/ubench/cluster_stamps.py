@@ -14,10 +14,16 @@ cells = L.workspace(lib.vts_lstm_cells_bytes(B, T, H), dev)
 hseq = torch.empty(B, T, H, device=dev); h_last = torch.empty(B, H, device=dev)
 w_hh = (torch.rand(4 * H, H, device=dev) * 2 - 1) / 16
 wsb = lib.vts_lstm_recurrent_workspace_bytes(B, T, H); ws = L.workspace(wsb, dev)
+planes = len(sys.argv) > 1 and sys.argv[1] == "planes"      # the path the models take: h sequence as planes only
+hp = L.workspace(lib.vts_lstm_planes_bytes(B, T, H, 1), dev)
 for it in range(3):
-    L.check(lib.vts_lstm_recurrent_fwd(L.wptr(gates), L.wptr(cells), L.ptr(hseq), L.ptr(h_last), None, L.ptr(w_hh), L.wptr(ws), wsb, B, T, H, 1, L.stream()), "fwd")
+    if planes:
+        L.check(lib.vts_lstm_recurrent_fwd_planes(L.wptr(gates), L.wptr(cells), None, L.wptr(hp), L.ptr(h_last), None, L.ptr(w_hh),
+                                                  L.wptr(ws), wsb, B, T, H, 1, L.stream()), "fwd")
+    else:
+        L.check(lib.vts_lstm_recurrent_fwd(L.wptr(gates), L.wptr(cells), L.ptr(hseq), L.ptr(h_last), None, L.ptr(w_hh), L.wptr(ws), wsb, B, T, H, 1, L.stream()), "fwd")
 torch.cuda.synchronize()
-off = (4 * H * H * 4 + 255) // 256 * 256 + (B // 128) * 8 * 32 * 4
+off = wsb - 256 - ((B // 16) * 512 + 255) // 256 * 256     # the launch's status word; the stamps follow it
 raw = ws[off:off + 128].cpu()
 print("err word", raw[:4].view(torch.int32).item())
 st = raw[8:72].view(torch.int64).tolist()

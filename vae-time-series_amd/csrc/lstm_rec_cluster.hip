@@ -148,9 +148,8 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) gnext[mt][ct] = ld_stream(G + gblock(mt, t, ct >> 1, ct & 1));
   };
-  auto load_g_part = [&](int t, int part) {      // blocks 2*part, 2*part + 1 of the sixteen
-#pragma unroll
-    for (int i = 2 * part; i < 2 * part + 2; ++i) gnext[i >> 3][i & 7] = ld_stream(G + gblock(i >> 3, t, (i & 7) >> 1, i & 1));
+  auto load_g_one = [&](int t, int i) {          // block i of the sixteen
+    gnext[i >> 3][i & 7] = ld_stream(G + gblock(i >> 3, t, (i & 7) >> 1, i & 1));
   };
   load_g(0);
   __syncthreads();   // image slice and `dead` in place
@@ -290,9 +289,14 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
             for (int p = 0; p < 2; ++p)
               *reinterpret_cast<u32x4*>(hp_tile(mt, t - 1, p) + pl_off) = a[ks % 3][mt][p];
         }
-        if (ct == 2) load_g_part(tnext, ks);     // the last step re-reads its own blocks: no branch in the product
+        // The next step's gate pre-activations (HBM): one block per group over the last two k-steps, behind the
+        // last h fragment loads - vector memory loads complete in issue order, so earlier in the product they hold
+        // up the fragments (L2) queued behind them.  (The last step re-reads its own blocks: no branch here.)
+        if (ks >= KS - 2) load_g_one(tnext, (ks - (KS - 2)) * CT + ct);
+#ifndef VTS_C_NOSTORE
         if (ct == 4) store_part(t - 1, 2 * ks);
         if (ct == 6) store_part(t - 1, 2 * ks + 1);
+#endif
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
           acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks % 3][mt][1]), frag(bh[slot]), acc[mt][ct], 0, 0, 0);
