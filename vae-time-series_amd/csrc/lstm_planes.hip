@@ -30,8 +30,18 @@ __global__ __launch_bounds__(256) void rows_to_planes_kernel(const float* __rest
     const long b = bt * 16 + r;
     const int c0 = cb * 32 + g * 8;
     float v[8];
+    const float* px = x + (b * T + t) * C + c0;
+    if (b < B && c0 + 8 <= C && (reinterpret_cast<uintptr_t>(px) & 7) == 0) {     // the usual case: four 8-byte loads
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (b < B && c0 + e < C) ? x[(b * T + t) * C + c0 + e] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const float2 w2 = *reinterpret_cast<const float2*>(px + 2 * e);
+        v[2 * e] = w2.x;
+        v[2 * e + 1] = w2.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (b < B && c0 + e < C) ? px[e] : 0.f;
+    }
     gp::u32x4 hi, lo;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
