@@ -528,7 +528,7 @@ def launch_ranks(a):
 
 
 # kernel of each timed entry point whose HBM traffic --traffic reports (substring of the rocprofv3 kernel name)
-TRAFFIC_KERNELS = {"lstm_recurrent_bwd": "lstm_rec3_bwd_kernel", "lstm_recurrent_fwd": "lstm_rec3c_fwd_kernel",
+TRAFFIC_KERNELS = {"lstm_recurrent_bwd": "lstm_rec3_bwd", "lstm_recurrent_fwd": "lstm_rec3c_fwd_kernel",
                    "lstm_wgrad_pair": "wgrad_planes_kernel", "lstm_inproj_fwd": "rowgemm_planes_kernel",
                    "lstm_dgrad": "rowgemm_planes_kernel"}
 
@@ -757,7 +757,10 @@ def main():
         # LDS and moves h through the L2 instead: per step and workgroup 128 KiB read + 16 KiB written.)
         cluster_fwd = (a.mode == "bf16x3" and a.H == 256 and a.batch % 128 == 0
                        and os.environ.get("VTS_LSTM_CLUSTER", "1")[:1] != "0")
-        for name, resident in (("lstm_recurrent_fwd", 0.125 if a.H >= 128 else 0.0), ("lstm_recurrent_bwd", 0.0)):
+        # (resident: the share of the image a workgroup keeps on chip - an eighth in LDS forward; backward an eighth
+        # in registers, in the hidden-256 bf16x3 kernel only)
+        bwd_resident = 0.125 if (a.mode == "bf16x3" and a.H == 256 and os.environ.get("VTS_LSTM_STAGED_BWD", "1")[:1] != "0") else 0.0
+        for name, resident in (("lstm_recurrent_fwd", 0.125 if a.H >= 128 else 0.0), ("lstm_recurrent_bwd", bwd_resident)):
             if name in kernels:
                 nwg = (a.batch + 15) // 16
                 byts = (a.T - 1) * nwg * 4.0 * a.H * a.H * 4 * (1.0 - resident)
