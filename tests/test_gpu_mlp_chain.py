@@ -50,6 +50,7 @@ CASES = [
     (530, 256, [(128, RELU), (64, RELU_DROP)], 32, [NONE, NONE, EXP, CLAMP, NONE], True),         # three-component heads
     (5, 16, [(20, RELU), (36, NONE), (8, RELU_DROP)], 7, [RELU], True),                           # odd widths, three layers
     (33, 32, [(128, RELU), (500, RELU_DROP)], 4, [NONE], False),                                  # eval mode: no mask
+    (20000, 64, [(128, RELU), (64, RELU_DROP)], 32, [EXP, CLAMP], True),                          # weight gradients in three row chunks
 ]
 
 
@@ -82,7 +83,7 @@ def test_chain_matches_torch(B, K, trunk_spec, L, head_acts, drop):
     xg = x.to(dev).requires_grad_(True)
     pg = [(w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True), a) for w, b, a in trunk + heads]
     kg = [None if k is None else k.to(dev) for k in keeps]
-    assert F.mlp_chain_usable(xg, pg[:len(trunk)], pg[len(trunk):])
+    assert F.mlp_chain_usable(xg, pg[:len(trunk)], pg[len(trunk):]) == (B <= F.CHAIN_MAX_ROWS)   # the model code's gate
     outs_g = F.mlp_chain(xg, pg[:len(trunk)], pg[len(trunk):], kg, 0.3)
     sum((o * w.to(dev)).sum() for o, w in zip(outs_g, wout)).backward()
 

@@ -216,8 +216,28 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, co
 // One workgroup per 16 x 16 tile of some dW = dpre^T . input, contracted over all rows: its four waves take every
 // fourth group of 16 rows (four groups in flight each) and their partial tiles are added up through LDS in a fixed
 // order.
+// Batches beyond DW_ROWS rows: blockIdx.y takes a chunk of the rows and the tiles go to `part` as
+// [chunk][tile][256 accumulator values in lane order, 16 bias sums] for mlp_chain_dw_reduce_kernel.
+constexpr int DW_ROWS = 8192;
+constexpr int DW_PART = 272;
+struct TileAt { int mi, N, K, n0, k0; };
+__device__ __forceinline__ TileAt tile_at(const Chain& D, const ChainBwd& R, int tile) {
+  TileAt t;
+  t.mi = 0;
+  while (tile >= R.tile0[t.mi + 1]) ++t.mi;
+  const bool head = t.mi >= D.n_trunk;
+  t.N = head ? D.head_dim : D.dim[t.mi];
+  const int srcl = head ? D.n_trunk - 1 : t.mi - 1;
+  t.K = srcl >= 0 ? D.dim[srcl] : D.in_dim;
+  const int ktiles = (t.K + 15) >> 4;
+  const int i = tile - R.tile0[t.mi];
+  t.n0 = (i / ktiles) << 4;
+  t.k0 = (i % ktiles) << 4;
+  return t;
+}
+
 __global__ __launch_bounds__(256) void mlp_chain_bwd_dw_kernel(const Chain D, const ChainBwd R, const float* __restrict__ x,
-                                                               long ldx, int B) {
+                                                               long ldx, int B, float* __restrict__ part) {
   __shared__ float red[3][64][5];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -240,16 +260,18 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dw_kernel(const Chain D, co
   const float* srcc = src + (k < K ? k : K - 1);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  const int row_beg = blockIdx.y * DW_ROWS;
+  const int row_end = part != nullptr ? min(B, row_beg + DW_ROWS) : B;
   auto fetch = [&](int row0, f32x4& av, f32x4& bv) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const long row = row0 + 4 * q + e;
-      const bool in = row < B;
+      const bool in = row < row_end;
       av[e] = in ? dpc[row * ldd] : 0.f;
       bv[e] = in ? srcc[row * lds_] : 0.f;
     }
   };
-  for (int row0 = 16 * wave; row0 < B; row0 += 256) {
+  for (int row0 = row_beg + 16 * wave; row0 < row_end; row0 += 256) {
     f32x4 av[4], bv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) fetch(row0 + 64 * u, av[u], bv[u]);
@@ -272,16 +294,38 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dw_kernel(const Chain D, co
     for (int i = 0; i < 4; ++i) acc[i] += red[w][lane][i];
     bsum += red[w][lane][4];
   }
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  if (part != nullptr) {
+    float* p = part + ((long)blockIdx.y * gridDim.x + tile) * DW_PART;
+    *reinterpret_cast<f32x4*>(p + lane * 4) = acc;
+    if (q == 0) p[256 + r] = bsum;
+    return;
+  }
   float* dw = R.dw[mi];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int nn = n0 + 4 * q + reg;
     if (nn < N && k < K) dw[(long)nn * K + k] = acc[reg];
   }
-  if (k0 == 0 && R.db[mi] != nullptr) {
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    if (q == 0 && n < N) R.db[mi][n] = bsum;
+  if (k0 == 0 && R.db[mi] != nullptr && q == 0 && n < N) R.db[mi][n] = bsum;
+}
+
+// chunks of one tile added up in a fixed order and written where the one-chunk kernel writes them
+__global__ __launch_bounds__(320) void mlp_chain_dw_reduce_kernel(const Chain D, const ChainBwd R, const float* __restrict__ part,
+                                                                  int ntiles, int nchunks) {
+  const int tile = blockIdx.x, e = threadIdx.x;
+  if (e >= DW_PART) return;
+  const TileAt t = tile_at(D, R, tile);
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += part[((long)c * ntiles + tile) * DW_PART + e];
+  if (e < 256) {
+    const int lane = e >> 2, reg = e & 3;
+    const int nn = t.n0 + 4 * (lane >> 4) + reg, k = t.k0 + (lane & 15);
+    if (nn < t.N && k < t.K) R.dw[t.mi][(long)nn * t.K + k] = s;
+  } else {
+    const int n = t.n0 + (e - 256);
+    if (t.k0 == 0 && R.db[t.mi] != nullptr && n < t.N) R.db[t.mi][n] = s;
   }
 }
 
@@ -307,6 +351,17 @@ static int chain_check(const vts_mlp_chain_desc* d, long B) {
   }
   for (int i = 0; i < d->n_heads; ++i) VTS_REQUIRE(d->head_act[i] >= 0 && d->head_act[i] <= 3, "mlp chain: head activation %d", d->head_act[i]);
   return VTS_OK;
+}
+
+// 16 x 16 output tiles of all weight gradients of a chain
+static int chain_tiles(const vts_mlp_chain_desc* d) {
+  int tiles = 0;
+  for (int i = 0; i < d->n_trunk + d->n_heads; ++i) {
+    const int N = i < d->n_trunk ? d->trunk_dim[i] : d->head_dim;
+    const int K = i == 0 ? d->in_dim : (i <= d->n_trunk ? d->trunk_dim[i - 1] : (d->n_trunk ? d->trunk_dim[d->n_trunk - 1] : d->in_dim));
+    tiles += ((N + 15) / 16) * ((K + 15) / 16);
+  }
+  return tiles;
 }
 
 static void chain_fill(Chain& D, const vts_mlp_chain_desc* d) {
@@ -354,7 +409,10 @@ size_t vts_mlp_chain_bwd_workspace_bytes_impl(const vts_mlp_chain_desc* d, long 
   if (chain_check(d, B) != VTS_OK) return 0;
   size_t n = (size_t)d->n_heads * d->head_dim;
   for (int i = 0; i < d->n_trunk; ++i) n += (size_t)d->trunk_dim[i];
-  return n * (size_t)B * sizeof(float) + 256;
+  size_t bytes = n * (size_t)B * sizeof(float) + 512;
+  const long nchunks = (B + DW_ROWS - 1) / DW_ROWS;
+  if (nchunks > 1) bytes += (size_t)nchunks * chain_tiles(d) * DW_PART * sizeof(float);
+  return bytes;
 }
 
 int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx, long B, const float* const* w,
@@ -400,7 +458,14 @@ int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_bwd_dx_kernel), CHAIN_LDS, &lds_done, "mlp_chain_bwd_dx")) return rc;
   hipLaunchKernelGGL(mlp_chain_bwd_dx_kernel, dim3((unsigned)((B + TM - 1) / TM)), dim3(256), CHAIN_LDS, st, D, R, (int)B);
   VTS_CHECK_LAUNCH("mlp_chain_bwd_dx");
-  hipLaunchKernelGGL(mlp_chain_bwd_dw_kernel, dim3((unsigned)tiles), dim3(256), 0, st, D, R, x, ldx, (int)B);
+  const int nchunks = (int)((B + DW_ROWS - 1) / DW_ROWS);
+  float* part = nullptr;
+  if (nchunks > 1) part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws + (size_t)B * d->n_heads * d->head_dim) + 255) & ~uintptr_t(255));
+  hipLaunchKernelGGL(mlp_chain_bwd_dw_kernel, dim3((unsigned)tiles, (unsigned)nchunks), dim3(256), 0, st, D, R, x, ldx, (int)B, part);
   VTS_CHECK_LAUNCH("mlp_chain_bwd_dw");
+  if (nchunks > 1) {
+    hipLaunchKernelGGL(mlp_chain_dw_reduce_kernel, dim3((unsigned)tiles), dim3(320), 0, st, D, R, part, tiles, nchunks);
+    VTS_CHECK_LAUNCH("mlp_chain_dw_reduce");
+  }
   return VTS_OK;
 }

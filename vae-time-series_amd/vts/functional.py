@@ -23,6 +23,10 @@ _MODE = 0  # dtype_mode of the C ABI passed to the LSTM GEMM stages
 _FUSED_CHAINS = os.environ.get("VTS_FUSED_CHAINS", "1")[:1] != "0"
 
 
+# Beyond this many rows the layers run one by one on the tiled GEMMs: the chain's weight-gradient kernel re-reads its
+# operand columns once per 16 x 16 output tile, which is nothing at 4096 rows (0.12 ms for the whole chain) and
+# more than the GEMMs' split-K plans at 65 536 (measured: 9.4 ms per step fused against 8.4 ms layer by layer).
+CHAIN_MAX_ROWS = 16384
 # test aid: when a dict, mlp_chain stores the trunk outputs of every chain it runs under the names it was given
 CHAIN_TAPS = None
 
@@ -438,6 +442,8 @@ class _MlpChain(torch.autograd.Function):
 def mlp_chain_usable(x, trunk, heads) -> bool:
     """Whether vts_mlp_chain_* takes this chain (widths and alignment; see include/vts.h)."""
     if not _FUSED_CHAINS or x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        return False
+    if x.shape[0] > CHAIN_MAX_ROWS:
         return False
     dims = [x.shape[1]] + [w.shape[0] for w, _, _ in trunk]
     if any(v % 4 or v > 512 for v in dims) or len(trunk) > 3 or not 1 <= len(heads) <= 8:
