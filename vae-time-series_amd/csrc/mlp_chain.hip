@@ -85,14 +85,20 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(const Chain D, const
       const bool nvalid = n < Nw;
       const float* wrow = D.w[mi] + (long)(nvalid ? n : Nw - 1) * K + 4 * q;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int k0 = 0; k0 < K; k0 += 16) {
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
-        if (k0 + 4 * q < K) {                                // K is a multiple of 4: a float4 is all in or all out
-          bv = *reinterpret_cast<const f32x4*>(wrow + k0);
-          av = *reinterpret_cast<const f32x4*>(&sa[cur][r][k0 + 4 * q]);
+      for (int kc = 0; kc < K; kc += 128) {                    // eight groups of 16 k: all weight loads first
+        f32x4 av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k0 = kc + 16 * u;
+          av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          bv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (k0 + 4 * q < K) {                                // K is a multiple of 4: a float4 is all in or all out
+            bv[u] = *reinterpret_cast<const f32x4*>(wrow + k0);
+            av[u] = *reinterpret_cast<const f32x4*>(&sa[cur][r][k0 + 4 * q]);
+          }
         }
-        acc = mfma4(av, bv, acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma4(av[u], bv[u], acc);
       }
       const float bias = D.b[mi] != nullptr ? D.b[mi][nvalid ? n : Nw - 1] : 0.f;
       const int act = heads ? D.hact[mi - D.n_trunk] : D.act[li];
@@ -163,23 +169,41 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, co
       for (int tile = wave; tile < ktiles; tile += 4) {
         const int k = (tile << 4) + r;
         const int kc = k < K ? k : K - 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int n0 = 0; n0 < Nin; n0 += 16) {
-          f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
-          const int nb = n0 + 4 * q;
-          if (nb < Nin) {
-            av = *reinterpret_cast<const f32x4*>(&sd[cur][r][nb]);
+        // this tile's saved activations (for the activation derivative) are fetched with the weights, not after
+        f32x4 aprev = {0.f, 0.f, 0.f, 0.f};
+        if (li >= 0 && k < K) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int n = nb + e;
-              if (n < Nin) {
-                const float* W = from_heads ? D.w[D.n_trunk + n / L] + (long)(n % L) * K : D.w[li + 1] + (long)n * K;
-                bv[e] = W[kc];
+          for (int reg = 0; reg < 4; ++reg) {
+            const long row = m0 + 4 * q + reg;
+            if (row < B) aprev[reg] = D.tout[li][row * K + k];
+          }
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // eight groups of 16 n at a time: their 32 weight loads (4 bytes per lane, rows K floats apart) are all
+        // issued before the first product, so a tile costs a memory latency per eight groups, not per group
+        for (int nc = 0; nc < Nin; nc += 128) {
+          f32x4 av[8], bv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int nb = nc + 16 * u + 4 * q;
+            // the 16 n of a group belong to one matrix (several heads: their width is a multiple of 16), so the
+            // pointer is picked with a wave-uniform index - a per-lane index into the argument struct would send
+            // the struct to scratch memory
+            const int hh = (from_heads && D.n_heads > 1) ? (nc + 16 * u) / L : 0;
+            const float* Wb = (from_heads ? D.w[D.n_trunk + hh] : D.w[li + 1]) + kc;
+            if (nb < Nin) {
+              av[u] = *reinterpret_cast<const f32x4*>(&sd[cur][r][nb]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int n = nb + e;
+                if (n < Nin) bv[u][e] = Wb[(long)(n - hh * L) * K];
               }
             }
           }
-          acc = mfma4(av, bv, acc);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = mfma4(av[u], bv[u], acc);
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, co
           const bool live = k < K && row < B;
           float v = acc[reg];
           if (li >= 0) {
-            const float a = live ? D.tout[li][row * K + k] : 0.f;
+            const float a = aprev[reg];
             const int act = D.act[li];
             if (act == 1) v = a > 0.f ? v : 0.f;
             else if (act == 4) v = a != 0.f ? v * (D.keep[li] != nullptr ? D.keep_scale : 1.f) : 0.f;
