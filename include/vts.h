@@ -476,6 +476,13 @@ int vts_adam_step_counted(float* param, const float* grad, float* exp_avg, float
                           int64_t* step_state, float lr, float beta1, float beta2, float eps, float grad_scale,
                           vts_stream_t stream);
 
+/* dst[dst_offset[c] .. + numel[c]) = src[c] for c < count (src[c] NULL: zeros): the gradients autograd produced, one
+ * tensor a parameter, into the flat gradient buffer the optimizer and the all-reduce work on (the flat-buffer
+ * counterpart of optimizer.step() reading p.grad: gaussian-lstm-DE.py:155, gpd-lstm-DE.py:104,
+ * mixture-vae-DE.py:163).  src, numel, dst_offset are host arrays; one launch per 40 chunks. */
+int vts_gather_chunks(const float* const* src, const int64_t* numel, const int64_t* dst_offset, int64_t count,
+                      float* dst, vts_stream_t stream);
+
 /* out[i] = in[i] * (*scalar) */
 int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream);
 

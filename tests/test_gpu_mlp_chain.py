@@ -126,3 +126,41 @@ def test_models_agree_with_and_without_fused_chains():
     assert l1 == l1 and abs(l0 - l1) <= 1e-5 * abs(l1)
     for n in g0:
         assert _rel(g0[n], g1[n]) < 1e-4, n
+
+
+def test_gather_chunks_and_flat_gradients():
+    """vts_gather_chunks (gradient tensors -> flat buffer: aligned, unaligned and missing sources) and the train-step
+    path that uses it: after a step the flat gradient equals the parameters' .grad, slot by slot."""
+    import ctypes as C
+    import vts
+    from vts import _lib as L
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    g = torch.Generator().manual_seed(0)
+    big = torch.randn(5000, generator=g).to(dev)
+    srcs = [torch.randn(1031, generator=g).to(dev), None, big[1:1 + 777], torch.randn(4, generator=g).to(dev), big[8:8 + 64]]
+    sizes = [1031, 50, 777, 4, 64]
+    offs, o = [], 8
+    for n in sizes:
+        offs.append(o)
+        o += (n + 3) // 4 * 4 + 4
+    dst = torch.full((o,), 7.0, device=dev)
+    n = len(srcs)
+    L.check(lib.vts_gather_chunks(L.ptr_array(srcs), (C.c_int64 * n)(*sizes), (C.c_int64 * n)(*offs), n, L.ptr(dst), L.stream()),
+            "vts_gather_chunks")
+    want = torch.full((o,), 7.0, device=dev)
+    for s, k, off in zip(srcs, sizes, offs):
+        want[off:off + k] = 0.0 if s is None else s
+    assert torch.equal(dst, want)
+
+    torch.manual_seed(1)
+    model = vts.build_model("gaussian", 4, 16, 8, 1).to(dev)
+    model.train()
+    opt = vts.Adam(vts.FlatParameters(model), lr=0.0)          # lr 0: the step leaves the parameters alone
+    x, y = torch.randn(32, 5, 4, device=dev), torch.randn(32, 1, device=dev)
+    vts.train_step(model, opt, x, y)
+    flat = opt.flat
+    assert not flat.pending
+    for p, off in zip(flat.params, flat.offsets):
+        assert p.grad is not None
+        assert torch.equal(flat.grad[off:off + p.numel()], p.grad.reshape(-1))

@@ -1000,6 +1000,59 @@ int vts_ew_colsum_rows(const float* a, long lda, int M, int N, float* part, hipS
   return VTS_OK;
 }
 
+// ---- gradients of many parameters into one flat buffer -----------------------------------------------------------
+// Up to GATHER_MAX chunks a launch: dst[off[c] .. off[c] + n[c]) = src[c] (zeros where src[c] is null).  blockIdx.y
+// = chunk, so the table is indexed with a wave-uniform value and stays in the kernel-argument segment.
+namespace {
+constexpr int GATHER_MAX = 40;
+struct GatherArgs {
+  const float* src[GATHER_MAX];
+  long n[GATHER_MAX];
+  long off[GATHER_MAX];
+};
+__global__ __launch_bounds__(256) void gather_chunks_kernel(const GatherArgs A, float* __restrict__ dst) {
+  const int c = blockIdx.y;
+  const float* __restrict__ s = A.src[c];
+  float* __restrict__ d = dst + A.off[c];
+  const long n = A.n[c];
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == nullptr) {
+    for (long i = start; i < n; i += stride) d[i] = 0.f;
+    return;
+  }
+  if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+    const long n4 = n >> 2;
+    for (long i = start; i < n4; i += stride)
+      reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(s)[i];
+    for (long i = (n4 << 2) + start; i < n; i += stride) d[i] = s[i];
+  } else {
+    for (long i = start; i < n; i += stride) d[i] = s[i];
+  }
+}
+}  // namespace
+
+int vts_ew_gather_chunks(const float* const* src, const long long* numel, const long long* dst_off, long count,
+                         float* dst, hipStream_t st) {
+  for (long c0 = 0; c0 < count; c0 += GATHER_MAX) {
+    const int m = (int)((count - c0) < GATHER_MAX ? (count - c0) : GATHER_MAX);
+    GatherArgs A{};
+    long nmax = 1;
+    for (int i = 0; i < m; ++i) {
+      A.src[i] = src[c0 + i];
+      A.n[i] = (long)numel[c0 + i];
+      A.off[i] = (long)dst_off[c0 + i];
+      if (A.n[i] > nmax) nmax = A.n[i];
+    }
+    int bx = vts_cdiv(nmax, 4 * 256 * 4);      // four float4 per thread in the largest chunk
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(gather_chunks_kernel, dim3(bx, m), dim3(256), 0, st, A, dst);
+    VTS_CHECK_LAUNCH("gather_chunks");
+  }
+  return VTS_OK;
+}
+
 int vts_ew_scale(const float* in, const float* s, float* out, long n, hipStream_t st) {
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, s, out, n);
   VTS_CHECK_LAUNCH("scale");

@@ -138,6 +138,8 @@ int vts_ew_act_bwd(int kind, const float* dy, const float* y, const float* aux, 
 int vts_ew_colsum_chunks(int M);
 int vts_ew_colsum_rows(const float* a, long lda, int M, int N, float* part, hipStream_t st);
 int vts_ew_scale(const float* in, const float* s, float* out, long n, hipStream_t st);
+int vts_ew_gather_chunks(const float* const* src, const long long* numel, const long long* dst_off, long count,
+                         float* dst, hipStream_t st);
 int vts_ew_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                 float bc1, float bc2_sqrt, float gscale, hipStream_t st);
 int vts_ew_tile16_convert(const float* rows, float* tiled, int B, int T, int N, int to_rows, hipStream_t st);
@@ -998,6 +1000,16 @@ int vts_adam_step_counted(float* param, const float* grad, float* exp_avg, float
 int vts_scale(const float* in, const float* scalar, float* out, int64_t n, vts_stream_t stream) {
   VTS_REQUIRE(in && scalar && out && n > 0, "scale: bad arguments");
   return vts_ew_scale(in, scalar, out, n, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_gather_chunks(const float* const* src, const int64_t* numel, const int64_t* dst_offset, int64_t count,
+                      float* dst, vts_stream_t stream) {
+  VTS_REQUIRE(src && numel && dst_offset && dst && count >= 0, "gather_chunks: bad arguments");
+  for (int64_t i = 0; i < count; ++i)
+    VTS_REQUIRE(numel[i] >= 0 && dst_offset[i] >= 0, "gather_chunks: negative size or offset in chunk %lld", (long long)i);
+  if (count == 0) return VTS_OK;
+  return vts_ew_gather_chunks(src, reinterpret_cast<const long long*>(numel), reinterpret_cast<const long long*>(dst_offset),
+                              (long)count, dst, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- fused head / decoder chains (mlp_chain.hip); vts_mlp_chain and vts_mlp_chain_desc have the same layout

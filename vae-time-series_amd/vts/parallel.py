@@ -78,6 +78,7 @@ class DataParallelTrainer:
                 if s <= off < e:
                     self._bucket_of[pi] = bi
         self._counts = [sum(1 for b in self._bucket_of.values() if b == bi) for bi in range(len(self.buckets))]
+        self._params_of = [[pi for pi, b in sorted(self._bucket_of.items()) if b == bi] for bi in range(len(self.buckets))]
         if self.distributed:   # also with a 1-rank group: the collective path is the same code
             for pi, p in enumerate(self.flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(pi))
@@ -92,6 +93,7 @@ class DataParallelTrainer:
                 s, e = self.buckets[bi]
                 if self.trace:
                     self.events.append(("allreduce", bi))
+                self.flat.gather_grads(self._params_of[bi])      # the bucket's gradients into the flat buffer
                 self._pending.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM,
                                                      group=self.group, async_op=True))
         return hook
@@ -118,10 +120,14 @@ class DataParallelTrainer:
                     s, e = self.buckets[bi]
                     if self.trace:
                         self.events.append(("allreduce", bi))
+                    self.flat.gather_grads(self._params_of[bi])
                     self._pending.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
             for work in self._pending:
                 work.wait()
+            self.flat.pending = False       # every bucket was gathered on its way to the collective
+        else:
+            self.flat.gather_grads()
         if apply_update:
             self.opt.step(grad_scale=1.0 / self.world)
         return loss.detach()

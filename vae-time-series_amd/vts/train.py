@@ -34,6 +34,8 @@ class FlatParameters:
         device = self.params[0].device
         self.data = torch.zeros(off, device=device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        self.pending = False        # release_grads was called and gather_grads has not run since
+        self._tables = None
         for p, o in zip(self.params, self.offsets):
             view = self.data[o:o + p.numel()].view_as(p)
             view.copy_(p.data)
@@ -46,6 +48,71 @@ class FlatParameters:
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def release_grads(self) -> None:
+        """Detach the parameters' gradients from the flat buffer: autograd then hands every parameter the gradient
+        tensor its backward node produced (no accumulation kernel per parameter), and gather_grads copies them
+        into the flat buffer with one launch."""
+        for p in self.params:
+            p.grad = None
+        self.pending = True
+
+    def gather_grads(self, indices: Optional[Iterable[int]] = None) -> None:
+        """flat.grad[slot of p] = p.grad for the given parameters (all by default); zeros where a parameter got no
+        gradient, nothing where the gradient already lives in its slot."""
+        if indices is None and self.grad.is_cuda and self._gather_all():
+            return
+        idx = list(range(len(self.params))) if indices is None else list(indices)
+        base = self.grad.data_ptr()
+        srcs, sizes, offs = [], [], []
+        for i in idx:
+            p, o = self.params[i], self.offsets[i]
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * o:
+                continue
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                g = g.to(torch.float32).contiguous()
+            srcs.append(g)
+            sizes.append(p.numel())
+            offs.append(o)
+        if indices is None:
+            self.pending = False
+        if not srcs:
+            return
+        if not self.grad.is_cuda:
+            # host tensors: the world-size-2 gloo test of the data-parallel logic, which runs stock CPU modules
+            for g, n, o in zip(srcs, sizes, offs):
+                if g is None:
+                    self.grad[o:o + n].zero_()
+                else:
+                    self.grad[o:o + n].copy_(g.reshape(-1))
+            return
+        import ctypes as C
+        lib = L.load()
+        n = len(srcs)
+        L.check(lib.vts_gather_chunks(L.ptr_array(srcs), (C.c_int64 * n)(*sizes), (C.c_int64 * n)(*offs), n,
+                                      L.ptr(self.grad), L.stream()), "vts_gather_chunks")
+
+    def _gather_all(self) -> bool:
+        """gather_grads() for all parameters with the size and offset tables built once (a gradient that already
+        lives in its slot is copied onto itself); False if some gradient needs converting first."""
+        import ctypes as C
+        n = len(self.params)
+        if self._tables is None:
+            self._tables = ((C.c_void_p * n)(), (C.c_int64 * n)(*[p.numel() for p in self.params]),
+                            (C.c_int64 * n)(*self.offsets))
+        ptrs, sizes, offs = self._tables
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                ptrs[i] = None
+            elif g.dtype is torch.float32 and g.is_contiguous():
+                ptrs[i] = g.data_ptr()
+            else:
+                return False
+        L.check(L.load().vts_gather_chunks(ptrs, sizes, offs, n, L.ptr(self.grad), L.stream()), "vts_gather_chunks")
+        self.pending = False
+        return True
 
     def span(self, first: int, last: int):
         """[start, end) float offsets covering parameters first..last (inclusive)."""
@@ -65,7 +132,9 @@ class Adam:
         self.step_state: Optional[torch.Tensor] = None   # device-side counter (see count_on_device)
 
     def zero_grad(self) -> None:
-        self.flat.zero_grad()
+        """optimizer.zero_grad(): the parameters' .grad become None (set_to_none, torch's default); step() collects
+        what backward left there."""
+        self.flat.release_grads()
 
     def count_on_device(self) -> None:
         """Keep the step counter in device memory from now on, so that a recorded step can be replayed
@@ -77,6 +146,8 @@ class Adam:
     def step(self, grad_scale: float = 1.0) -> None:
         lib = L.load()
         f = self.flat
+        if f.pending:
+            f.gather_grads()
         if self.step_state is not None:
             L.check(lib.vts_adam_step_counted(L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                               f.numel, L.wptr(self.step_state), self.lr, self.betas[0], self.betas[1],
