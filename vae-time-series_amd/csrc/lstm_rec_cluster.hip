@@ -111,8 +111,18 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
   }
   // the cluster's exchange buffers as a buffer resource: 16-byte accesses with the sc1 bit (aux 16), which go
   // around the CU's L1 like the agent-scope atomics the flags use, and which the compiler's wait counting sees
+  // With plane output the plane buffer itself is the exchange medium: member c's h_t tiles (column block c of the
+  // cluster's eight window tiles) are what its peers load as the fragments of k-step c, and every step has its own
+  // slot, so h is written once and no separate exchange buffer is touched.
+  const bool planes = hp.base != nullptr;
+  const long hp_cluster_bytes = 8L * hp.ts * hp.ncb * 2 * gp::TILE_B;      // the cluster's eight window tiles
   const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(xchg + (size_t)q * (X_CLUSTER / 8), 0, (int)X_CLUSTER, 0x00020000);
+      planes ? __builtin_amdgcn_make_buffer_rsrc(hp.base + hp.tile((long)q * 8, -hp.t0, 0, 0), 0, (int)hp_cluster_bytes, 0x00020000)
+             : __builtin_amdgcn_make_buffer_rsrc(xchg + (size_t)q * (X_CLUSTER / 8), 0, (int)X_CLUSTER, 0x00020000);
+  // byte offset in xrsrc of the 1 KiB block (window tile rt of the cluster, k-step / column block ks, plane p) of h_t
+  auto hp_block = [&](int rt, int t, int ks, int p) -> int {
+    return (int)(((((long)rt * hp.ts + hp.t0 + t) * hp.ncb + ks) * 2 + p) * gp::TILE_B);
+  };
   unsigned* fq = flags + (size_t)q * NC * FLAG_STRIDE;
 
   f32x4 cst[2][2];
@@ -122,10 +132,8 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
     for (int jl = 0; jl < 2; ++jl) cst[mt][jl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Plane output of the h sequence (hp.base != null; gemm_planes.h): member c owns column block c (its 32 hidden
-  // units) of every tile.  The fragments of k-step c that a step's product loads from the exchange buffer are the
-  // tiles of h_{t-1} for this wave's two window tiles, so they are stored as they are used; the last step's h is
-  // copied out of the staging planes at the end, and slot 0 (the zero initial state) is cleared here.
-  const bool planes = hp.base != nullptr;
+  // units) of every tile and writes it when it publishes h_t; the last step's h (never published) is copied out of
+  // the staging planes at the end, and slot 0 (the zero initial state) is cleared here.
   const unsigned pl_off = gp::slot(g, r) * 16;
   auto hp_tile = [&](int mt, int t, int p) -> char* {
     return hp.base + hp.tile((long)q * 8 + 2 * wave + mt, t, c, p);
@@ -239,7 +247,8 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const int off = xin_off + p * X_PLANE + ((2 * wave + mt) * KS + ks) * 1024 + lane * 16;
+          const int off = planes ? hp_block(2 * wave + mt, t - 1, ks, p) + (int)pl_off
+                                 : xin_off + p * X_PLANE + ((2 * wave + mt) * KS + ks) * 1024 + lane * 16;
           a[ks % 3][mt][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 16));
         }
     };
@@ -282,13 +291,6 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
         // fragments two k-steps ahead, two blocks of the next step's gates and two sixteenths of the previous
         // step's bulk stores (gates, cells, h sequence; they read act, hv and cst, which the cell update
         // further down overwrites) per k-step.
-        if (ct == 1 && planes && ks == c) {      // tiles of h_{t-1}, column block c
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-              *reinterpret_cast<u32x4*>(hp_tile(mt, t - 1, p) + pl_off) = a[ks % 3][mt][p];
-        }
         // The next step's gate pre-activations (HBM): one block per group over the last two k-steps, behind the
         // last h fragment loads - vector memory loads complete in issue order, so earlier in the product they hold
         // up the fragments (L2) queued behind them.  (The last step re-reads its own blocks: no branch here.)
@@ -347,8 +349,9 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
         const int idx = tid + 256 * i;    // [plane 2][rt 8][lane 64]
         const int p = idx >> 9, rt = (idx >> 6) & 7, l = idx & 63;
         const u32x4 v = *reinterpret_cast<const u32x4*>(stage + p * S_PLANE + (rt * 16 + (l & 15)) * 64 + (l >> 4) * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, v), xrsrc,
-                                               xout_off + p * X_PLANE + (rt * KS + c) * 1024 + l * 16, 0, 16);
+        const int off = planes ? hp_block(rt, t, c, p) + gp::slot(l >> 4, l & 15) * 16
+                               : xout_off + p * X_PLANE + (rt * KS + c) * 1024 + l * 16;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, v), xrsrc, off, 0, 16);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -695,6 +698,11 @@ size_t vts_lstm_rec3c_flag_bytes(int B) { return ((size_t)(B / CROWS) * NC + 1) 
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
                        void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream) {
   const int nclusters = B / CROWS;
+  // the kernel addresses a cluster's part of the plane buffer with 32-bit offsets
+  if (h_planes != nullptr && 8L * (T + 1) * 8 * 2 * gp::TILE_B >= (1L << 31)) {
+    vts_set_error("lstm_rec3c_fwd: %d steps are too many for the cluster kernel's plane addressing", T);
+    return VTS_ERR_UNSUPPORTED;
+  }
   static vts_lds_mask lds_done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), C_LDS, &lds_done, "lstm_rec3c_fwd"))
     return rc;
