@@ -112,6 +112,12 @@ int vts_lstm_recurrent_bwd(float* gates, const float* cells, const float* dh_seq
                            float* db_ih, float* db_hh, int accumulate, void* workspace,
                            size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
                            vts_stream_t stream);
+/* Status of the last vts_lstm_recurrent_bwd / _bwd_planes / vts_lstm_layer_bwd launch that used `workspace`, as
+ * vts_lstm_recurrent_fwd_status: 0 = completed; 2 = a workgroup of the bench-sized backward kernel gave up waiting
+ * for its peer's partial sums: the gate gradients and bias gradients then hold NaN.  (No counterpart in the
+ * reference.) */
+int vts_lstm_recurrent_bwd_status(const void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H,
+                                  int32_t* status, vts_stream_t stream);
 /* dx_t16 <- dgates . w_ih (gradient w.r.t. the layer input sequence; Cin % 16 == 0) */
 int vts_lstm_dgrad(const float* dgates, const float* w_ih, float* dx_t16, int64_t B, int64_t T,
                    int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream);
@@ -187,6 +193,15 @@ void vts_debug_set_cluster_bwd(int on);
  * stages them through LDS a step ahead and keeps an eighth of the packed W_hh image in registers (5 % faster at
  * the bench shape).  Same arithmetic in the same order: identical results. */
 void vts_debug_set_staged_bwd(int on);
+/* Development switch, process-wide: on = 0 keeps vts_lstm_recurrent_bwd_planes off the bench-sized backward kernel in
+ * which two workgroups share 32 windows, each holding the rows of W_hh of half the hidden units and handing the
+ * other the partial sums for its half of dh every step (default on, unless VTS_LSTM_PAIR_BWD=0 is set at
+ * start-up; taken for hidden 256, B a multiple of 32 and a grid that is resident at once).  Same results as the
+ * one-workgroup kernels up to the order of the fp32 sums. */
+void vts_debug_set_pair_bwd(int on);
+/* Test hook, process-wide: member `member` (0 or 1) of every such pair withholds what it owes its peer and the
+ * waits are cut short, so the timeout path (vts_lstm_recurrent_bwd_status) can be exercised; -1 = off (default). */
+void vts_debug_set_pair_fault(int member);
 
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,

@@ -39,21 +39,24 @@ def _planes_taken(B, T, C, H):
     (384, 4, 64, 256, 2),     # 96 token tiles: output tiles spread unevenly over the workgroups
     (1024, 8, 256, 256, 3),   # 512 token tiles: more than one output tile per workgroup, 32 k-slices
 ])
-@pytest.mark.parametrize("need_output,bwd_kernel", [(True, "staged"), (False, "staged"), (True, "direct"),
-                                                    (False, "direct"), (False, "cluster")])
+@pytest.mark.parametrize("need_output,bwd_kernel", [(True, "pair"), (False, "pair"), (True, "staged"), (False, "staged"),
+                                                    (True, "direct"), (False, "direct"), (False, "cluster")])
 def test_plane_path_matches_torch_lstm(B, T, C, H, layers, need_output, bwd_kernel):
-    """The three backward recurrence kernels of this shape: "staged" (default: saved tensors through LDS a step
-    ahead, part of W_hh resident in registers), "direct" (saved tensors loaded into registers at the top of a
-    step's product: vts_debug_set_staged_bwd(0)), "cluster" (clusters of eight workgroups that exchange the gate
-    gradients through the plane buffer: vts_debug_set_cluster_bwd(1))."""
+    """The four backward recurrence kernels of this shape: "pair" (default: two workgroups share 32 windows and half
+    of W_hh each, partial sums of dh handed over every step), "staged" (one workgroup per 16 windows, saved tensors
+    through LDS a step ahead, part of W_hh resident in registers: vts_debug_set_pair_bwd(0)), "direct" (saved tensors
+    loaded into registers at the top of a step's product: vts_debug_set_staged_bwd(0)), "cluster" (clusters of eight
+    workgroups that exchange the gate gradients through the plane buffer: vts_debug_set_cluster_bwd(1))."""
     import vts
     from vts import _lib
     assert _planes_taken(B, T, C, H)
+    _lib.load().vts_debug_set_pair_bwd(1 if bwd_kernel == "pair" else 0)
     _lib.load().vts_debug_set_cluster_bwd(1 if bwd_kernel == "cluster" else 0)
     _lib.load().vts_debug_set_staged_bwd(0 if bwd_kernel == "direct" else 1)
     try:
         _run_plane_case(B, T, C, H, layers, need_output)
     finally:
+        _lib.load().vts_debug_set_pair_bwd(1)
         _lib.load().vts_debug_set_cluster_bwd(0)
         _lib.load().vts_debug_set_staged_bwd(1)
 

@@ -82,6 +82,12 @@ int vts_planes_wgrad(const void* dg_planes, const void* s_planes, int x_zero_slo
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
                        void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream);
 size_t vts_lstm_rec3c_bwd_flag_bytes(int B);
+bool vts_lstm_rec3p_usable(int B, int T, int H);
+size_t vts_lstm_rec3p_xchg_bytes(int B);
+void vts_lstm_rec3p_set_fault(int member);
+int vts_lstm_rec3p_bwd(const float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
+                       float* dbpart, const float* W_hh, float* Wp, void* dg_planes, void* xws, unsigned* err, int B, int T,
+                       hipStream_t stream);
 int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
                        float* dbpart, const float* W_hh, float* Wp, void* dg_planes, void* fws, unsigned* err, int B, int T,
                        hipStream_t stream);
@@ -198,9 +204,15 @@ static size_t rec_ws_seed_bytes(int64_t B, int64_t H) { return round256((size_t)
 // [packed W_hh image][bias-gradient partials][dh_T in tile16 order][dc_T in tile16 order]
 // ... [status word of the launch, 256 B][hand-off flags of the backward cluster kernel: four 128-byte lines per 16 windows]
 static size_t rec_ws_bflag_bytes(int64_t B) { return round256((size_t)(pad16(B) / 16) * 512); }
+// ... [exchange buffer of the backward pair kernel: hidden 256 and whole pairs of window tiles, up to the largest
+// batch whose grid can be resident at once on any device this library runs on]
+static size_t rec_ws_pair_bytes(int64_t B, int64_t H) {
+  return (H == 256 && B % 32 == 0 && B <= 16384) ? round256(vts_lstm_rec3p_xchg_bytes((int)B)) : 0;
+}
 size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
   (void)T;
-  return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H) + 256 + rec_ws_bflag_bytes(B);
+  return rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) + 2 * rec_ws_seed_bytes(B, H) + 256 + rec_ws_bflag_bytes(B) +
+         rec_ws_pair_bytes(B, H);
 }
 static unsigned* rec_ws_status(void* workspace, int64_t B, int64_t H) {
   return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + rec_ws_pack_bytes(H) + rec_ws_dbpart_bytes(B, H) +
@@ -305,6 +317,11 @@ int vts_lstm_recurrent_fwd_status(const void* workspace, size_t workspace_bytes,
   return VTS_OK;
 }
 
+int vts_lstm_recurrent_bwd_status(const void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H,
+                                  int32_t* status, vts_stream_t stream) {
+  return vts_lstm_recurrent_fwd_status(workspace, workspace_bytes, B, T, H, status, stream);
+}
+
 int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_last, float* c_last, const float* w_hh,
                            void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t H, int dtype_mode,
                            vts_stream_t stream) {
@@ -316,6 +333,9 @@ int vts_lstm_recurrent_fwd(float* gates, float* cells, float* hseq, float* h_las
 static std::atomic<int> g_cluster_bwd{[] { const char* e = getenv("VTS_LSTM_CLUSTER_BWD"); return (e && e[0] == '1') ? 1 : 0; }()};
 void vts_debug_set_cluster_bwd(int on) { g_cluster_bwd.store(on ? 1 : 0); }
 void vts_debug_set_staged_bwd(int on) { vts_lstm_rec3_set_staged_bwd(on); }
+static std::atomic<int> g_pair_bwd{[] { const char* e = getenv("VTS_LSTM_PAIR_BWD"); return (e && e[0] == '0') ? 0 : 1; }()};
+void vts_debug_set_pair_bwd(int on) { g_pair_bwd.store(on ? 1 : 0); }
+void vts_debug_set_pair_fault(int member) { vts_lstm_rec3p_set_fault(member); }
 
 static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
                               const float* dc_last, const float* w_hh, float* db_ih, float* db_hh, int accumulate,
@@ -348,7 +368,20 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
     // times the forward kernel's h, and a CU's vector memory pipe moves the 610 KiB a step then needs no faster
     // than the 1 MiB weight image of the one-workgroup kernel.)
     int rc = VTS_ERR_UNSUPPORTED;
-    if (dg_planes && g_cluster_bwd.load() > 0 && vts_lstm_rec3c_usable((int)B, (int)T, (int)H)) {
+    // first choice at bench size: pairs of workgroups that split W_hh and the hidden units between them
+    // (lstm_rec_pair.hip; VTS_LSTM_PAIR_BWD=0 at start-up or vts_debug_set_pair_bwd(0) turns it off)
+    if (dg_planes && g_pair_bwd.load() > 0 && g_cluster_bwd.load() == 0 && rec_ws_pair_bytes(B, H) > 0 &&
+        vts_lstm_rec3p_usable((int)B, (int)T, (int)H)) {
+      unsigned* status = rec_ws_status(workspace, B, H);
+      if (hipMemsetAsync(status, 0, sizeof(unsigned), st) != hipSuccess) {
+        vts_set_error("lstm_recurrent_bwd: clearing the status word failed");
+        return VTS_ERR_HIP;
+      }
+      rc = vts_lstm_rec3p_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, dg_planes,
+                              reinterpret_cast<char*>(status) + 256 + rec_ws_bflag_bytes(B), status, (int)B, (int)T, st);
+      if (rc != VTS_OK && rc != VTS_ERR_UNSUPPORTED) return rc;
+    }
+    if (rc == VTS_ERR_UNSUPPORTED && dg_planes && g_cluster_bwd.load() > 0 && vts_lstm_rec3c_usable((int)B, (int)T, (int)H)) {
       unsigned* status = rec_ws_status(workspace, B, H);
       if (hipMemsetAsync(status, 0, sizeof(unsigned), st) != hipSuccess) {
         vts_set_error("lstm_recurrent_bwd: clearing the status word failed");

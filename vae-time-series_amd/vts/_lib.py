@@ -55,6 +55,9 @@ SIGNATURES = {
     "vts_debug_set_cluster_fault": (None, [_int]),
     "vts_debug_set_cluster_bwd": (None, [_int]),
     "vts_debug_set_staged_bwd": (None, [_int]),
+    "vts_debug_set_pair_bwd": (None, [_int]),
+    "vts_debug_set_pair_fault": (None, [_int]),
+    "vts_lstm_recurrent_bwd_status": (_int, [_ptr, _sz, _i64, _i64, _i64, _ptr, _ptr]),
     "vts_lstm_recurrent_bwd": (_int, [_ptr] * 8 + [_int, _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_dgrad": (_int, [_ptr] * 3 + [_i64, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_wgrad": (_int, [_ptr, _ptr, _int, _ptr, _int, _ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
