@@ -47,6 +47,18 @@ constexpr int XW = NI * 1024;                 // bytes one wave publishes per st
 constexpr int XSLOTS = 3;
 constexpr int X_PAIR = XSLOTS * 2 * 4 * XW;   // [slot][destination member][wave] = 96 KiB per pair
 constexpr unsigned EMPTY = 0xffffffffu;
+#ifndef VTS_RP_PUB_AUX
+#define VTS_RP_PUB_AUX 16
+#endif
+#ifndef VTS_RP_RST_AUX
+#define VTS_RP_RST_AUX 16
+#endif
+#ifndef VTS_RP_PAY_AT
+#define VTS_RP_PAY_AT 11
+#endif
+#ifndef VTS_RP_LD_AUX
+#define VTS_RP_LD_AUX 16
+#endif
 
 typedef unsigned pvec4 __attribute__((vector_size(16)));
 __device__ __forceinline__ bf16x8 pfrag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -95,6 +107,7 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
   constexpr int NB = NB_G + NB_C + (DH ? NI : 0);      // LDS-DMA loads per batch
   constexpr int RES = 4;                               // units of the image resident in registers: 4, 5, 14, 15
   constexpr bool RING_AG = true;                       // the ring lives in accumulator registers (the arch VGPRs serve the cell arithmetic)
+  constexpr int PAY_AT = VTS_RP_PAY_AT;                // the read of the peer's half is issued after this unit
   constexpr int PRE = NI - 1;                          // blocks whose coefficients are worked out inside the product
   static_assert(3 * UT + NB <= 63, "vmcnt is a six-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smemp[];
@@ -141,25 +154,22 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
   auto dma = [&](unsigned lds_off, const float* src) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_off), "v"(voff), "s"(src) : "memory", "m0");
   };
-  // the batch of step t: G_t, c_{t-1} and dh_t of this wave's four blocks into staging.  Always NB loads.
-  auto issue_batch = [&](int t) {
+  // the batch of step t: G_t, c_{t-1} and dh_t of this wave's four blocks into staging, block by block (the cell
+  // phase issues a block's share between its own blocks: issued back to back, the 24 loads of a wave hold up
+  // the wave for as long as the CU's memory path needs to take them).  Always NB loads per step.
+  auto issue_block = [&](int i, int t) {
     const int tc = t >= 1 ? t - 1 : 0;
+    const long bt = bt0 + (i >> 1);
+    const int jt = jt0 + (i & 1);
+    const float* Gt = G + ((bt * T + t) * (4 * PJT) + jt) * 256;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const long bt = bt0 + (i >> 1);
-      const int jt = jt0 + (i & 1);
-      const float* Gt = G + ((bt * T + t) * (4 * PJT) + jt) * 256;
+    for (int k = 0; k < 4; ++k) dma(stg_lds + (i * 4 + k) * 1024, Gt + (long)(k * PJT) * 256);
+    dma(stg_lds + (NB_G + i) * 1024, cseq + ((bt * T + tc) * PJT + jt) * 256);
+    if (DH) dma(stg_lds + (NB_G + NB_C + i) * 1024, dhseq + ((bt * T + t) * PJT + jt) * 256);
+  };
+  auto issue_batch = [&](int t) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dma(stg_lds + (i * 4 + k) * 1024, Gt + (long)(k * PJT) * 256);
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-      dma(stg_lds + (NB_G + i) * 1024, cseq + (((bt0 + (i >> 1)) * T + tc) * PJT + jt0 + (i & 1)) * 256);
-    if (DH) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-        dma(stg_lds + (NB_G + NB_C + i) * 1024, dhseq + (((bt0 + (i >> 1)) * T + t) * PJT + jt0 + (i & 1)) * 256);
-    }
+    for (int i = 0; i < NI; ++i) issue_block(i, t);
   };
 
   // coefficients of the cell backward that do not depend on dh (see lstm_rec3_bwd_staged_kernel)
@@ -207,6 +217,9 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
       kf[i][reg] = gf[reg];
       tcn[i][reg] = fast_tanh(cp[reg]);
     }
+    // computed here, not where the cell phase first uses them (the optimiser sinks arithmetic past the branches of
+    // the exchange otherwise - out of the product, where it is free, into the critical path behind it)
+    asm volatile("" : "+v"(kA[i]), "+v"(kO[i]), "+v"(kI[i]), "+v"(kF[i]), "+v"(kG[i]), "+v"(kf[i]), "+v"(tcn[i]));
   };
   auto take_dh = [&] {
     asm volatile("" ::: "memory");
@@ -220,9 +233,10 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
 
   // cell backward of this wave's four blocks: gate gradients as bf16 planes into LDS (column 4 * local hidden +
   // gate, 16-byte chunks XOR-ed with the row), their plane tiles read back in fragment order and stored
-  auto cell_bwd = [&](int t) {
+  auto cell_bwd = [&](int t, int tnext) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
+      issue_block(i, tnext);                     // (the staging area is free: every coefficient is in registers)
       const int mt = i >> 1, jl = i & 1;
       const int jloc = 2 * wave + jl;            // hidden tile within the member's half
       unsigned char* const da_m = da_s + mt * PLANE_M;
@@ -263,45 +277,70 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     }
   };
 
+  // Pairs start a quarter of a step apart: in lockstep every CU of the device would ask the HBM for its saved
+  // tensors in the same fifth of the step (and the L2 for W_hh in the rest); staggered, the demand is even.
+#ifndef VTS_RP_SKEW
+#define VTS_RP_SKEW 78
+#endif
+  for (int k = 0; k < (q & 3); ++k) __builtin_amdgcn_s_sleep(VTS_RP_SKEW);
 #pragma unroll
   for (int i = 0; i < NI; ++i) premath(i, T - 1);
   take_dh();
-  issue_batch(T >= 2 ? T - 2 : 0);
-  cell_bwd(T - 1);
+  cell_bwd(T - 1, T >= 2 ? T - 2 : 0);
 
+#ifdef VTS_RP_STAMP
+  // timing experiments: ticks per phase, summed over the steps, written over the first bias-gradient partials
+  long long pstamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long pprev = clock64();
+#define PSTAMP(i) do { const long long now = clock64(); pstamp[i] += now - pprev; pprev = now; } while (0)
+#else
+#define PSTAMP(i)
+#endif
   int slot = 0;
   for (int t = T - 2; t >= 0; --t) {
+    PSTAMP(9);                                    // (cell backward of the step before)
     wg_barrier();                                 // dA_{t+1} is complete
+    PSTAMP(0);
     f32x4 acc[NI];
+    u32x4 fa_h[2], fa_l[2];                       // A fragments (hi, lo plane) of window tile 0 / 1
     auto lds_a = [&](int plane, int mt, int ks) {
       return *reinterpret_cast<const u32x4*>(da_s + (plane * 2 + mt) * PLANE_M + r * ROWB + (((4 * ks + g) ^ r) << 4));
     };
-    // one unit = two k-steps of this wave's two output tiles for both window tiles: 24 MFMAs; allowed < 0: resident
-    auto unit = [&](u32x4 (&w)[UT], int u, auto allowed) {
+    // one unit = two k-steps of this wave's two output tiles for both window tiles: 24 MFMAs; allowed < 0: resident.
+    // The A fragments run one group of six MFMAs ahead: while window tile 0's products issue, tile 1's fragments
+    // of the same k-step are on their way from LDS, and while tile 1's issue, tile 0's of the next k-step (kn = the
+    // unit that runs next, -1 = none).  One window tile at a time: its two output tiles alternate, a dependent
+    // MFMA is two issues away.
+    auto unit = [&](u32x4 (&w)[UT], int u, int kn, auto allowed) {
 #pragma unroll
       for (int kl = 0; kl < 2; ++kl) {
         const int ks = 2 * (u & 7) + kl;
-        u32x4 ah = lds_a(0, 0, ks), al = lds_a(1, 0, ks);
+        fa_h[1] = lds_a(0, 1, ks);
+        fa_l[1] = lds_a(1, 1, ks);
         if constexpr (decltype(allowed)::value >= 0) {
           if (kl == 0) w_wait<decltype(allowed)::value, UT, RING_AG>(w);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // one window tile at a time (its two output tiles alternate: a dependent MFMA is two issues away)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int jl = 0; jl < 2; ++jl)
-            acc[2 * mt + jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag(al), pfrag(w[kl * 4 + jl]), acc[2 * mt + jl], 0, 0, 0);
+            acc[2 * mt + jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag(fa_l[mt]), pfrag(w[kl * 4 + jl]), acc[2 * mt + jl], 0, 0, 0);
 #pragma unroll
           for (int jl = 0; jl < 2; ++jl)
-            acc[2 * mt + jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag(ah), pfrag(w[kl * 4 + 2 + jl]), acc[2 * mt + jl], 0, 0, 0);
-          if (mt == 0) al = lds_a(1, 1, ks);
+            acc[2 * mt + jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag(fa_h[mt]), pfrag(w[kl * 4 + 2 + jl]), acc[2 * mt + jl], 0, 0, 0);
 #pragma unroll
           for (int jl = 0; jl < 2; ++jl)
-            acc[2 * mt + jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag(ah), pfrag(w[kl * 4 + jl]), acc[2 * mt + jl], 0, 0, 0);
-          if (mt == 0) ah = lds_a(0, 1, ks);
+            acc[2 * mt + jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag(fa_h[mt]), pfrag(w[kl * 4 + jl]), acc[2 * mt + jl], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (mt == 0) {
+            const int nks = kl == 0 ? ks + 1 : (kn >= 0 ? 2 * (kn & 7) : -1);
+            if (nks >= 0) {
+              fa_h[0] = lds_a(0, 0, nks);
+              fa_l[0] = lds_a(1, 0, nks);
+            }
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     };
     // Queue on entry, oldest first: units 0..3 in w0..w3 (issued during the previous product; landed - the wait
@@ -315,62 +354,89 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     constexpr std::integral_constant<int, -1> resident{};
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fa_h[0] = lds_a(0, 0, 0);
+    fa_l[0] = lds_a(1, 0, 0);
     // ---- first pass: the peer's 128 outputs
-    unit(w0, 0, first);
+    unit(w0, 0, 1, first);
     w_issue<UT, RING_AG>(w0, unit_ptr(6), voff);
-    unit(w1, 1, first);
+    unit(w1, 1, 2, first);
     w_issue<UT, RING_AG>(w1, unit_ptr(7), voff);
-    unit(w2, 2, first);
+    unit(w2, 2, 3, first);
     w_issue<UT, RING_AG>(w2, unit_ptr(8), voff);
-    unit(w3, 3, first);
+    unit(w3, 3, 4, first);
     w_issue<UT, RING_AG>(w3, unit_ptr(9), voff);
-    unit(wr[0], 4, resident);
-    unit(wr[1], 5, resident);
-    unit(w0, 6, steady);
+    PSTAMP(1);
+    unit(wr[0], 4, 5, resident);
+    unit(wr[1], 5, 6, resident);
+    PSTAMP(2);
+    unit(w0, 6, 7, steady);
     w_issue<UT, RING_AG>(w0, unit_ptr(10), voff);
     premath(0, t);
     __builtin_amdgcn_sched_barrier(0);
-    unit(w1, 7, steady);
+    unit(w1, 7, 8, steady);
     w_issue<UT, RING_AG>(w1, unit_ptr(11), voff);
     // ---- publish it
     const int xs = slot * (2 * 4 * XW);
     if (m != mute_member) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pvec4, acc[i]), xrsrc, xs + tx0 + i * 1024, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pvec4, acc[i]), xrsrc, xs + tx0 + i * 1024, 0, VTS_RP_PUB_AUX);
     }
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(3);
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- second pass: the own 128 outputs
-    unit(w2, 8, steady);
-    w_issue<UT, RING_AG>(w2, unit_ptr(12), voff);
-    premath(1, t);
-    __builtin_amdgcn_sched_barrier(0);
-    unit(w3, 9, steady);
-    w_issue<UT, RING_AG>(w3, unit_ptr(13), voff);
-    unit(w0, 10, steady);
-    w_issue<UT, RING_AG>(w0, unit_ptr(0), voff);
-    premath(2, t);
-    __builtin_amdgcn_sched_barrier(0);
-    unit(w1, 11, steady);
-    w_issue<UT, RING_AG>(w1, unit_ptr(1), voff);
-    // the peer's contribution to this wave's outputs: asked for now, looked at when the pass is over
+    // the peer's contribution to this wave's outputs: asked for after unit PAY_AT, looked at when the pass is over
     pvec4 pay[NI];
     auto load_pay = [&] {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) pay[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xs + rx0 + i * 1024, 0, 16);
+      for (int i = 0; i < NI; ++i) pay[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xs + rx0 + i * 1024, 0, VTS_RP_LD_AUX);
     };
+    auto ask_peer = [&](auto after) {
+      if constexpr (decltype(after)::value == PAY_AT) {
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(4);
+        if (!dead) load_pay();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // ---- second pass: the own 128 outputs
+    unit(w2, 8, 9, steady);
+    w_issue<UT, RING_AG>(w2, unit_ptr(12), voff);
+    ask_peer(std::integral_constant<int, 8>{});
+    premath(1, t);
     __builtin_amdgcn_sched_barrier(0);
-    if (!dead) load_pay();
+    unit(w3, 9, 10, steady);
+    w_issue<UT, RING_AG>(w3, unit_ptr(13), voff);
+    ask_peer(std::integral_constant<int, 9>{});
+    unit(w0, 10, 11, steady);
+    w_issue<UT, RING_AG>(w0, unit_ptr(0), voff);
+    ask_peer(std::integral_constant<int, 10>{});
+    premath(2, t);
     __builtin_amdgcn_sched_barrier(0);
-    unit(w2, 12, steady);
+    unit(w1, 11, 12, steady);
+    w_issue<UT, RING_AG>(w1, unit_ptr(1), voff);
+    ask_peer(std::integral_constant<int, 11>{});
+    unit(w2, 12, 13, steady);
+#ifndef VTS_RP_LATE23
     w_issue<UT, RING_AG>(w2, unit_ptr(2), voff);
-    unit(w3, 13, steady);
+#endif
+    ask_peer(std::integral_constant<int, 12>{});
+    unit(w3, 13, 14, steady);
+#ifndef VTS_RP_LATE23
     w_issue<UT, RING_AG>(w3, unit_ptr(3), voff);
-    unit(wr[2], 14, resident);
-    unit(wr[3], 15, resident);
+#endif
+    ask_peer(std::integral_constant<int, 13>{});
+#ifdef VTS_RP_DRAIN13
+    PSTAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PSTAMP(13);
+#endif
+    unit(wr[2], 14, 15, resident);
+    unit(wr[3], 15, -1, resident);
+    ask_peer(std::integral_constant<int, 15>{});
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(5);
     if (!dead) {
       int spins = 0;
       for (;;) {
@@ -387,27 +453,38 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
         __builtin_amdgcn_s_sleep(1);
         load_pay();
       }
+#ifdef VTS_RP_STAMP
+      pstamp[10] += spins;
+#endif
     }
+    PSTAMP(6);
+#ifdef VTS_RP_LATE23
+    w_issue<UT, RING_AG>(w2, unit_ptr(2), voff);
+    w_issue<UT, RING_AG>(w3, unit_ptr(3), voff);
+#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const f32x4 p = dead ? f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}
                            : __builtin_bit_cast(f32x4, pay[i]);
       dh[i] = acc[i] + p;
     }
-    // the slot is EMPTY again for the step after next but one
-    if (!dead) {
+    // The slot is EMPTY again for the step after next but one.  (The sums above come first, pinned by the asm: the
+    // compiler waits for `pay` with counts that stores issued in between would turn into a wait for those stores -
+    // a write-through round trip.  A wave that gave up resets too: it no longer matters.)
+    asm volatile("" : "+v"(dh[0]), "+v"(dh[1]), "+v"(dh[2]), "+v"(dh[3]) :: "memory");
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        __builtin_amdgcn_raw_buffer_store_b128(pvec4{EMPTY, EMPTY, EMPTY, EMPTY}, xrsrc, xs + rx0 + i * 1024, 0, 16);
-    }
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_buffer_store_b128(pvec4{EMPTY, EMPTY, EMPTY, EMPTY}, xrsrc, xs + rx0 + i * 1024, 0, VTS_RP_RST_AUX);
     slot = slot == XSLOTS - 1 ? 0 : slot + 1;
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(11);
 #pragma unroll
     for (int i = PRE; i < NI; ++i) premath(i, t);
     take_dh();
-    issue_batch(t >= 1 ? t - 1 : 0);
+    PSTAMP(12);
     wg_barrier();                                 // every wave has read the last fragments of dA_{t+1}
-    cell_bwd(t);
+    PSTAMP(8);
+    cell_bwd(t, t >= 1 ? t - 1 : 0);
   }
   // keep the wrapped-around ring loads' registers live until they have landed
   w_wait<0, UT, RING_AG>(w0);
@@ -425,9 +502,18 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       if (dead) s = __builtin_nanf("");
+#ifdef VTS_RP_STAMP
+      s = 0.f;
+#endif
       if (g == 0) dbpart[bt * (4 * PH) + k * PH + jt * 16 + r] = s;
     }
   }
+#ifdef VTS_RP_STAMP
+  __syncthreads();
+  if (tid == 0)
+    for (int i = 0; i < 16; ++i) dbpart[(bt0 + m) * (4 * PH) + 128 * m + i] = (float)pstamp[i] / (float)(T - 1);
+#endif
+#undef PSTAMP
 }
 
 std::atomic<int> g_pair_fault{-1};
