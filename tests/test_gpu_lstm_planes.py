@@ -140,3 +140,35 @@ def test_second_backward_off_the_plane_path_raises():
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second backward"):
         loss.backward()
+
+
+def _pair_case(fault):
+    """One backward pass of a 2-layer LSTM at a shape the pair kernel takes, with the pair kernel's test hook set."""
+    import vts
+    from vts import _lib
+    lib = _lib.load()
+    dev = _dev()
+    torch.manual_seed(3)
+    lstm = vts.LSTM(8, 256, num_layers=2).to(dev)
+    x = torch.randn(128, 6, 8, device=dev)
+    lib.vts_debug_set_pair_fault(fault)
+    try:
+        out, (hn, _) = lstm(x)
+        (out.pow(2).sum() + hn.pow(2).sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.vts_debug_set_pair_fault(-1)
+    return {k: p.grad.clone() for k, p in lstm.named_parameters()}
+
+
+def test_pair_backward_with_a_missing_peer():
+    """A peer that never delivers its partial sums turns the gradients into NaN instead of hanging, and the next launch
+    is clean again."""
+    good = _pair_case(-1)
+    for k in good:
+        assert torch.isfinite(good[k]).all(), k
+    bad = _pair_case(1)
+    assert torch.isnan(bad["weight_hh_l1"]).any(), "a missed hand-off must poison the gradients"
+    again = _pair_case(-1)
+    for k in good:
+        assert torch.equal(good[k], again[k]), k

@@ -5,7 +5,8 @@ The ring buffers are filled by inline-asm global loads whose data arrives asynch
 kernel is only correct if, between a load and the hand-counted s_waitcnt that proves it landed,
 nothing reads or copies those registers.  This script compiles the source to assembly and checks
 for every recurrent kernel with such loads that no instruction (MFMA, move, spill, another load) touches a
-register written by such a load (`global_load_dwordx4 v[a:b] or a[a:b], vN, s[c:d] offset:K`) while the
+register written by such a load (`global_load_dwordx4 v[a:b] or a[a:b], vN, s[c:d] offset:K`, and the pair
+kernel's `buffer_load_dwordx4 v[a:b], vN, s[c:f], 0 offen ...` of its peer's partial sums) while the
 load can still be outstanding, which also re-derives every hand-counted vmcnt from the
 instruction stream.  Exit status 1 and a listing on any violation.
 
@@ -69,7 +70,8 @@ def check(name, body):
         if in_asm:
             from_asm.add(len(code))       # instruction text written by the kernel source, not the compiler
         code.append(l)
-    ring_re = re.compile(r"^global_load_dwordx4 ([va]\[\d+:\d+\]), v\d+, s\[\d+:\d+\]")
+    ring_re = re.compile(r"^(?:global_load_dwordx4 ([va]\[\d+:\d+\]), v\d+, s\[\d+:\d+\]"
+                         r"|buffer_load_dwordx4 ([va]\[\d+:\d+\]), v\d+, s\[\d+:\d+\], 0 offen)")
     is_ring = [bool(ring_re.match(l)) and i in from_asm for i, l in enumerate(code)]
     other_load_re = re.compile(r"^(global|buffer|scratch|flat)_load")
     if not any(is_ring):
@@ -109,7 +111,8 @@ def check(name, body):
             op = l.split()[0]
             inflight = set().union(*fifo) if fifo else set()
             if is_ring[i]:
-                dst = regs_of(ring_re.match(l).group(1))
+                mm = ring_re.match(l)
+                dst = regs_of(mm.group(1) or mm.group(2))
                 if dst & inflight and report and l not in seen:
                     seen.add(l)
                     bad.append(f"{name}: `{l}` reloads registers still in flight")

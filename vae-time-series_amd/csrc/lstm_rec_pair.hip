@@ -14,6 +14,9 @@
 // its own.  The peer's half goes out after the first pass; the other's arrives while the second pass runs.
 // There are no flags: a slot of the exchange buffer holds the pattern EMPTY until the producer's 16-byte stores
 // land, the consumer reads the slot (sc1 loads, around the L1) until no word of it is EMPTY and stores EMPTY back.
+// (Measured alternatives for two members that share an L2: plain stores change nothing - the sc1 read is the
+// slow part, about 3 000 clocks; a plain read behind `buffer_inv sc1` drops the W_hh image from the L2 and doubles
+// the step; behind `buffer_inv sc0` it returns stale lines of the L1.)
 // Three slots in rotation: between a reset and the producer's next store into the same slot lie a full drain of the
 // consumer's memory operations (the wait of the next step's read) and two hand-offs, so the reset cannot overtake it.
 // Reads are bounded: when the peer never shows up the wave goes on with NaN and sets the launch's status word.
@@ -47,19 +50,6 @@ constexpr int XW = NI * 1024;                 // bytes one wave publishes per st
 constexpr int XSLOTS = 3;
 constexpr int X_PAIR = XSLOTS * 2 * 4 * XW;   // [slot][destination member][wave] = 96 KiB per pair
 constexpr unsigned EMPTY = 0xffffffffu;
-#ifndef VTS_RP_PUB_AUX
-#define VTS_RP_PUB_AUX 16
-#endif
-#ifndef VTS_RP_RST_AUX
-#define VTS_RP_RST_AUX 16
-#endif
-#ifndef VTS_RP_PAY_AT
-#define VTS_RP_PAY_AT 11
-#endif
-#ifndef VTS_RP_LD_AUX
-#define VTS_RP_LD_AUX 16
-#endif
-
 typedef unsigned pvec4 __attribute__((vector_size(16)));
 __device__ __forceinline__ bf16x8 pfrag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -107,7 +97,7 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
   constexpr int NB = NB_G + NB_C + (DH ? NI : 0);      // LDS-DMA loads per batch
   constexpr int RES = 4;                               // units of the image resident in registers: 4, 5, 14, 15
   constexpr bool RING_AG = true;                       // the ring lives in accumulator registers (the arch VGPRs serve the cell arithmetic)
-  constexpr int PAY_AT = VTS_RP_PAY_AT;                // the read of the peer's half is issued after this unit
+  constexpr int PAY_AT = 11;                // the read of the peer's half is issued after this unit
   constexpr int PRE = NI - 1;                          // blocks whose coefficients are worked out inside the product
   static_assert(3 * UT + NB <= 63, "vmcnt is a six-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smemp[];
@@ -143,6 +133,11 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc(xchg + (size_t)q * X_PAIR, 0, X_PAIR, 0x00020000);
   const int tx0 = ((1 - m) * 4 + wave) * XW + lane * 16, rx0 = (m * 4 + wave) * XW + lane * 16;
+  // the same descriptor as four SGPRs, for the read that is issued as inline asm
+  const unsigned long long xbase = reinterpret_cast<unsigned long long>(xchg) + (unsigned long long)q * X_PAIR;
+  const u32x4 xdesc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xbase),
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32)) & 0xffffu, (unsigned)X_PAIR,
+                       0x00020000u};
   bool dead = false;
 
   // LDS traffic of this wave done, then the barrier (no fence: a fence would wait for the ring and the batch)
@@ -184,12 +179,17 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
   u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
 #pragma unroll
   for (int i = 0; i < UT; ++i) w0[i] = w1[i] = w2[i] = w3[i] = u32x4{0u, 0u, 0u, 0u};
+  // the resident units, loaded the way the ring is (as plain loads the compiler keeps guarding their registers with
+  // waits of its own inside the loop - counted on the operations it knows of, so far too strict)
   u32x4 wr[RES][UT];
 #pragma unroll
-  for (int i = 0; i < RES; ++i)
+  for (int i = 0; i < RES; ++i) {
 #pragma unroll
-    for (int j = 0; j < UT; ++j)
-      wr[i][j] = *reinterpret_cast<const u32x4*>(unit_ptr(i < 2 ? 4 + i : 12 + i) + j * 1024 + voff);
+    for (int j = 0; j < UT; ++j) wr[i][j] = u32x4{0u, 0u, 0u, 0u};
+    w_issue<UT, RING_AG>(wr[i], unit_ptr(i < 2 ? 4 + i : 12 + i), voff);
+  }
+#pragma unroll
+  for (int i = 0; i < RES; ++i) w_wait<0, UT, RING_AG>(wr[i]);
   w_issue<UT, RING_AG>(w0, unit_ptr(0), voff);
   w_issue<UT, RING_AG>(w1, unit_ptr(1), voff);
   w_issue<UT, RING_AG>(w2, unit_ptr(2), voff);
@@ -380,26 +380,33 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     if (m != mute_member) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pvec4, acc[i]), xrsrc, xs + tx0 + i * 1024, 0, VTS_RP_PUB_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pvec4, acc[i]), xrsrc, xs + tx0 + i * 1024, 0, 16);
     }
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(3);
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the peer's contribution to this wave's outputs: asked for after unit PAY_AT, looked at when the pass is over
+    // The peer's contribution to this wave's outputs: asked for after unit PAY_AT, looked at when the pass is over.
+    // The first read is inline asm with a counted wait, like the ring loads (left to the compiler the wait is
+    // vmcnt(0): a full L2 round trip for the two ring units issued behind the read); a read that finds the slot
+    // EMPTY is repeated the plain way.  Always issued, so the queue looks the same on every path.
     pvec4 pay[NI];
     auto load_pay = [&] {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) pay[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xs + rx0 + i * 1024, 0, VTS_RP_LD_AUX);
+      for (int i = 0; i < NI; ++i) pay[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xs + rx0 + i * 1024, 0, 16);
     };
     auto ask_peer = [&](auto after) {
       if constexpr (decltype(after)::value == PAY_AT) {
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(4);
-        if (!dead) load_pay();
+        const int vo = xs + rx0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 sc1" : "=v"(pay[i]) : "v"(vo), "s"(xdesc), "n"(i * 1024));
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    static_assert(PAY_AT == 11, "the wait below counts the ring loads issued behind the read: units 2 and 3 of the next step");
     // ---- second pass: the own 128 outputs
     unit(w2, 8, 9, steady);
     w_issue<UT, RING_AG>(w2, unit_ptr(12), voff);
@@ -418,25 +425,17 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     w_issue<UT, RING_AG>(w1, unit_ptr(1), voff);
     ask_peer(std::integral_constant<int, 11>{});
     unit(w2, 12, 13, steady);
-#ifndef VTS_RP_LATE23
     w_issue<UT, RING_AG>(w2, unit_ptr(2), voff);
-#endif
     ask_peer(std::integral_constant<int, 12>{});
     unit(w3, 13, 14, steady);
-#ifndef VTS_RP_LATE23
     w_issue<UT, RING_AG>(w3, unit_ptr(3), voff);
-#endif
     ask_peer(std::integral_constant<int, 13>{});
-#ifdef VTS_RP_DRAIN13
-    PSTAMP(5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PSTAMP(13);
-#endif
     unit(wr[2], 14, 15, resident);
     unit(wr[3], 15, -1, resident);
     ask_peer(std::integral_constant<int, 15>{});
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(5);
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(pay[0]), "+v"(pay[1]), "+v"(pay[2]), "+v"(pay[3]) : "n"(2 * UT));
     if (!dead) {
       int spins = 0;
       for (;;) {
@@ -458,10 +457,6 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
 #endif
     }
     PSTAMP(6);
-#ifdef VTS_RP_LATE23
-    w_issue<UT, RING_AG>(w2, unit_ptr(2), voff);
-    w_issue<UT, RING_AG>(w3, unit_ptr(3), voff);
-#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const f32x4 p = dead ? f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}
@@ -474,7 +469,7 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     asm volatile("" : "+v"(dh[0]), "+v"(dh[1]), "+v"(dh[2]), "+v"(dh[3]) :: "memory");
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_buffer_store_b128(pvec4{EMPTY, EMPTY, EMPTY, EMPTY}, xrsrc, xs + rx0 + i * 1024, 0, VTS_RP_RST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(pvec4{EMPTY, EMPTY, EMPTY, EMPTY}, xrsrc, xs + rx0 + i * 1024, 0, 16);
     slot = slot == XSLOTS - 1 ? 0 : slot + 1;
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(11);
