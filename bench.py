@@ -23,6 +23,7 @@ import gc
 import json
 import math
 import os
+import re
 import subprocess
 import sys
 import time
@@ -527,8 +528,9 @@ def launch_ranks(a):
     sys.exit(max(abs(rc) for rc in rcs))
 
 
-# kernel of each timed entry point whose HBM traffic --traffic reports (substring of the rocprofv3 kernel name)
-TRAFFIC_KERNELS = {"lstm_recurrent_bwd": "lstm_rec3_bwd", "lstm_recurrent_fwd": "lstm_rec3c_fwd_kernel",
+# kernel of each timed entry point whose HBM traffic --traffic reports (regular expression searched in the rocprofv3
+# kernel name; the backward recurrence has a pair, a cluster and two one-workgroup kernels)
+TRAFFIC_KERNELS = {"lstm_recurrent_bwd": "lstm_rec3[pc]?_bwd", "lstm_recurrent_fwd": "lstm_rec3c_fwd_kernel",
                    "lstm_wgrad_pair": "wgrad_planes_kernel", "lstm_inproj_fwd": "rowgemm_planes_kernel",
                    "lstm_dgrad": "rowgemm_planes_kernel"}
 
@@ -570,7 +572,7 @@ def measure_traffic(a):
             per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
         for (kname, _), v in per.items():
             for sub in set(TRAFFIC_KERNELS.values()):
-                if sub in kname:
+                if re.search(sub, kname):
                     ent = sums.setdefault(sub, {"FETCH_SIZE": [], "WRITE_SIZE": []})
                     ent[counter].append(v)
     shutil.rmtree(top, ignore_errors=True)
