@@ -138,7 +138,9 @@ struct RowPol {
         const long tt = (long)tb * 16 + wm * 4 + mt;
         f32x4 v = acc[mt][nt];
         v += bias;
-        *reinterpret_cast<f32x4*>(out + (tt * (N / 16) + ct) * 256 + lane * 4) = v;
+        // streaming store: the output is read again a kernel later at the earliest, and allocated in the L2 it
+        // would push out the operand tiles the column tiles of a token block share (input projection 0.72 -> 0.66 ms)
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (tt * (N / 16) + ct) * 256 + lane * 4));
       }
     }
   }
