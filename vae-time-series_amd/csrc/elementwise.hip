@@ -489,6 +489,54 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int j = threadIdx.x; j < 2 * H; j += blockDim.x) part[(long)blockIdx.x * 2 * H + j] = sm[j];
 }
 
+// Rows of NC * 64 columns (the encoder trunk's 256): a lane always sees the same NC columns, so the gamma / beta
+// gradients accumulate in registers and the four waves of a block meet once, in LDS, at the end (the kernel above
+// pays two LDS atomics per element).
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const float* __restrict__ dy,
+                                                                 const float* __restrict__ x, long ldx,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ dx,
+                                                                 long lddx, float* __restrict__ part, int M,
+                                                                 int rows_per_block) {
+  constexpr int H = NC * 64;
+  __shared__ float sm[4][2 * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[NC], ag[NC], ab[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { g[k] = gamma[lane + 64 * k]; ag[k] = 0.f; ab[k] = 0.f; }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (long)row * ldx;
+    const float* dyr = dy + (long)row * H;
+    float xh[NC], d[NC], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      xh[k] = (xr[lane + 64 * k] - mu) * rs;
+      d[k] = dyr[lane + 64 * k];
+      const float dxh = d[k] * g[k];
+      s1 += dxh;
+      s2 += dxh * xh[k];
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      dx[(long)row * lddx + lane + 64 * k] = rs * (d[k] * g[k] - s1 - xh[k] * s2);
+      ag[k] += d[k] * xh[k];
+      ab[k] += d[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { sm[wave][lane + 64 * k] = ag[k]; sm[wave][H + lane + 64 * k] = ab[k]; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * H; j += blockDim.x)
+    part[(long)blockIdx.x * 2 * H + j] = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
+}
+
 // Narrow rows (H = 4 * LPR <= 64, the transformer's d_model): LPR lanes share a row with one float4
 // each, so a wave covers 64/LPR rows per load instruction instead of one, the row statistics are
 // xor-shuffles inside the lane group, and the gamma/beta gradients accumulate in registers (each lane
@@ -957,7 +1005,7 @@ int vts_ew_layernorm_fwd(const float* x, long ldx, const float* gamma, const flo
 }
 
 int vts_ew_layernorm_bwd_blocks(int M) {
-  int b = vts_cdiv(M, 64);
+  int b = vts_cdiv(M, 16);
   if (b > 1024) b = 1024;
   return b < 1 ? 1 : b;
 }
@@ -971,6 +1019,13 @@ int vts_ew_layernorm_bwd(const float* dy, const float* x, long ldx, const float*
     else if (H == 32) hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<8>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
     else hipLaunchKernelGGL(layernorm_bwd_narrow_kernel<4>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
     VTS_CHECK_LAUNCH("layernorm_bwd_narrow");
+    return VTS_OK;
+  }
+  if (H == 256 || H == 128 || H == 64) {
+    if (H == 256) hipLaunchKernelGGL(layernorm_bwd_cols_kernel<4>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
+    else if (H == 128) hipLaunchKernelGGL(layernorm_bwd_cols_kernel<2>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
+    else hipLaunchKernelGGL(layernorm_bwd_cols_kernel<1>, dim3(blocks), dim3(256), 0, st, dy, x, ldx, gamma, mean, rstd, dx, lddx, part, M, rpb);
+    VTS_CHECK_LAUNCH("layernorm_bwd_cols");
     return VTS_OK;
   }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * H * sizeof(float), st, dy, x, ldx, gamma,
