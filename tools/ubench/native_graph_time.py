@@ -1,10 +1,11 @@
 """Development aid: ms per train step at the reference's own sizes (16 windows x 16 steps x 1 channel, hidden 64),
-launched one by one and replayed as a HIP graph."""
+launched one by one and replayed as a HIP graph.  VTS_MODE=bf16x3 selects the other arithmetic of the LSTM products."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "vae-time-series_amd"))
 import torch, vts
 dev = torch.device("cuda:0")
+vts.set_mode(os.environ.get("VTS_MODE", "f32"))
 B, T, C, H, L = [int(v) for v in (sys.argv[1:6] + [16, 16, 1, 64, 32][len(sys.argv) - 1:])]
 for kind in ("gaussian", "gpd", "mixture", "mixture3"):
     for graphed in (False, True):

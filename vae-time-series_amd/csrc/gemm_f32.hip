@@ -1197,7 +1197,11 @@ int vts_gemm_pick_ksplit(int M, int N, long K, int mode) {
   const bool big = split_plan_big(M, N, K, mode);
   const int tiles = vts_cdiv(M, big ? BMB : BM) * vts_cdiv(N, BN);
   const int slots_per_xcd = big ? 32 : 32 * (mode == 1 ? 3 : 4);   // bf16x3 kernel: 160 VGPRs -> 3 workgroups per CU
-  if (tiles >= 4 * slots_per_xcd || K <= 512) return 1;
+  if (tiles >= 4 * slots_per_xcd) return 1;
+  // A handful of output tiles and a short contraction (the reference's own sizes: 256 tokens): one workgroup per
+  // tile would walk the k loop alone, a memory latency per iteration (29 us for 256 x 64 x 256); slices of 64 run
+  // side by side instead and a small reduction adds them up.
+  if (K <= 512) return (tiles <= 8 && K >= 128) ? (int)((K + 63) / 64) : 1;
   long per_xcd = slots_per_xcd / tiles;
   if (per_xcd < 1) per_xcd = 1;
   long s = 8 * per_xcd;
