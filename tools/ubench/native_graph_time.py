@@ -4,6 +4,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "vae-time-series_amd"))
 import torch, vts
+if os.environ.get("VTS_LIB"):
+    from vts import _lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["VTS_LIB"])
 dev = torch.device("cuda:0")
 vts.set_mode(os.environ.get("VTS_MODE", "f32"))
 B, T, C, H, L = [int(v) for v in (sys.argv[1:6] + [16, 16, 1, 64, 32][len(sys.argv) - 1:])]

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vae-time-series_amd"))
 import torch, vts
 dev = torch.device("cuda:0")
+vts.set_mode(os.environ.get("VTS_MODE", "f32"))
 B, T, C, H, L = 16, 16, 1, 64, 32
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 torch.manual_seed(0)

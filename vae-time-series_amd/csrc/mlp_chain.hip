@@ -14,6 +14,7 @@
 // k of its row at a time (one float4) and feeds them to four MFMAs, so the k index a lane covers in a group of 16
 // is 4 * (l >> 4) + e - the same (permuted) order for both operands.
 #include "vts_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -55,7 +56,10 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(const Chain D, const float* __restrict__ x, long ldx, int B) {
+// NW waves per workgroup.  A wave walks its column tiles one after the other and each costs a memory latency (the
+// weights), so a batch of few row tiles - few workgroups - runs with more waves than four (WIDE_NW below).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_chain_fwd_kernel(const Chain D, const float* __restrict__ x, long ldx, int B) {
   extern __shared__ __attribute__((aligned(16))) float chain_lds[];
   float (*sa)[TM][LDA] = reinterpret_cast<float (*)[TM][LDA]>(chain_lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(const Chain D, const
   const int m0 = blockIdx.x * TM;
   {
     const int c4n = D.in_dim >> 2;
-    for (int idx = tid; idx < TM * c4n; idx += 256) {
+    for (int idx = tid; idx < TM * c4n; idx += NW * 64) {
       const int rr = idx / c4n, c4 = idx - rr * c4n;
       const long row = m0 + rr;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(const Chain D, const
     const int Nw = heads ? D.head_dim : D.dim[li];           // width of one matrix of this stage
     const int tpm = (Nw + 15) >> 4;                          // column tiles per matrix
     const int ntiles = heads ? D.n_heads * tpm : tpm;
-    for (int tile = wave; tile < ntiles; tile += 4) {
+    for (int tile = wave; tile < ntiles; tile += NW) {
       const int mi = heads ? D.n_trunk + tile / tpm : li;    // matrix index
       const int n0 = (heads ? tile % tpm : tile) << 4;
       const int n = n0 + r;
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(const Chain D, const
 }
 
 // ---- backward 1: gradients w.r.t. the pre-activations and the chain input ---------------------------------------
-__global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, const ChainBwd R, int B) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_chain_bwd_dx_kernel(const Chain D, const ChainBwd R, int B) {
   extern __shared__ __attribute__((aligned(16))) float chain_lds[];
   float (*sd)[TM][LDA] = reinterpret_cast<float (*)[TM][LDA]>(chain_lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, co
   const int L = D.head_dim, NH = D.n_heads * L;
   const int NHp = (NH + 15) & ~15;
   // head stage: d pre = d out * act'
-  for (int idx = tid; idx < TM * NHp; idx += 256) {
+  for (int idx = tid; idx < TM * NHp; idx += NW * 64) {
     const int m = idx / NHp, c = idx - m * NHp;
     const long row = m0 + m;
     float v = 0.f;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, co
     const int K = li >= 0 ? D.dim[li] : D.in_dim;
     if (li >= 0 || R.dx != nullptr) {
       const int ktiles = (K + 15) >> 4;
-      for (int tile = wave; tile < ktiles; tile += 4) {
+      for (int tile = wave; tile < ktiles; tile += NW) {
         const int k = (tile << 4) + r;
         const int kc = k < K ? k : K - 1;
         // this tile's saved activations (for the activation derivative) are fetched with the weights, not after
@@ -227,13 +232,23 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_dx_kernel(const Chain D, co
       // columns of the next stage's input beyond K, up to the next multiple of 16, must read as zero
       if (li >= 0) {
         const int Kp = (K + 15) & ~15;
-        for (int idx = tid; idx < TM * (Kp - K); idx += 256) sd[cur ^ 1][idx / (Kp - K)][K + idx % (Kp - K)] = 0.f;
+        for (int idx = tid; idx < TM * (Kp - K); idx += NW * 64) sd[cur ^ 1][idx / (Kp - K)][K + idx % (Kp - K)] = 0.f;
       }
     }
     __syncthreads();
     cur ^= 1;
     Nin = K;
   }
+}
+
+#ifndef VTS_CHAIN_NW
+#define VTS_CHAIN_NW 8
+#endif
+constexpr int WIDE_NW = VTS_CHAIN_NW;
+// WIDE_NW waves per workgroup up to this many rows (VTS_CHAIN_WIDE_ROWS overrides it, for measurements).
+bool chain_wide(long B) {
+  static const long lim = [] { const char* e = getenv("VTS_CHAIN_WIDE_ROWS"); return e ? atol(e) : 8192L; }();
+  return B <= lim;
 }
 
 // ---- backward 2: weight and bias gradients of every matrix of the chain -----------------------------------------
@@ -423,8 +438,15 @@ int vts_mlp_chain_fwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
     VTS_REQUIRE(d->head_act[i] != 3 || D.haux[i] != nullptr, "mlp chain: head %d clamps and needs its aux buffer", i);
   }
   static vts_lds_mask lds_done{0};
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_fwd_kernel), CHAIN_LDS, &lds_done, "mlp_chain_fwd")) return rc;
-  hipLaunchKernelGGL(mlp_chain_fwd_kernel, dim3((unsigned)((B + TM - 1) / TM)), dim3(256), CHAIN_LDS, st, D, x, ldx, (int)B);
+  if (chain_wide(B)) {
+    static vts_lds_mask lds_done_w{0};
+    if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<WIDE_NW>), CHAIN_LDS, &lds_done_w, "mlp_chain_fwd")) return rc;
+    hipLaunchKernelGGL(mlp_chain_fwd_kernel<WIDE_NW>, dim3((unsigned)((B + TM - 1) / TM)), dim3(WIDE_NW * 64), CHAIN_LDS, st, D, x, ldx, (int)B);
+    VTS_CHECK_LAUNCH("mlp_chain_fwd");
+    return VTS_OK;
+  }
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_fwd_kernel<4>), CHAIN_LDS, &lds_done, "mlp_chain_fwd")) return rc;
+  hipLaunchKernelGGL(mlp_chain_fwd_kernel<4>, dim3((unsigned)((B + TM - 1) / TM)), dim3(256), CHAIN_LDS, st, D, x, ldx, (int)B);
   VTS_CHECK_LAUNCH("mlp_chain_fwd");
   return VTS_OK;
 }
@@ -479,8 +501,14 @@ int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
   R.dx = dx;
   R.lddx = lddx;
   static vts_lds_mask lds_done{0};
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_bwd_dx_kernel), CHAIN_LDS, &lds_done, "mlp_chain_bwd_dx")) return rc;
-  hipLaunchKernelGGL(mlp_chain_bwd_dx_kernel, dim3((unsigned)((B + TM - 1) / TM)), dim3(256), CHAIN_LDS, st, D, R, (int)B);
+  if (chain_wide(B)) {
+    static vts_lds_mask lds_done_w{0};
+    if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_bwd_dx_kernel<WIDE_NW>), CHAIN_LDS, &lds_done_w, "mlp_chain_bwd_dx")) return rc;
+    hipLaunchKernelGGL(mlp_chain_bwd_dx_kernel<WIDE_NW>, dim3((unsigned)((B + TM - 1) / TM)), dim3(WIDE_NW * 64), CHAIN_LDS, st, D, R, (int)B);
+  } else {
+    if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(mlp_chain_bwd_dx_kernel<4>), CHAIN_LDS, &lds_done, "mlp_chain_bwd_dx")) return rc;
+    hipLaunchKernelGGL(mlp_chain_bwd_dx_kernel<4>, dim3((unsigned)((B + TM - 1) / TM)), dim3(256), CHAIN_LDS, st, D, R, (int)B);
+  }
   VTS_CHECK_LAUNCH("mlp_chain_bwd_dx");
   const int nchunks = (int)((B + DW_ROWS - 1) / DW_ROWS);
   float* part = nullptr;
