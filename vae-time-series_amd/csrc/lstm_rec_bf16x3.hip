@@ -135,9 +135,20 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
   const unsigned voff = lane * 16;
   // half-unit q of k-step ks: q = 0, 1 hi halves, 2, 3 lo halves
   auto hu_ptr = [&](int ks, int q) { return wbase + (size_t)((ks * 4 + q) * UT) * 1024; };
+  // Hidden 64: a wave's whole share of the image is 16 fragments (64 registers).  It is loaded once and stays; the
+  // ring below would wait for the L2 four times a k-step with six MFMAs in between (22 us for 16 steps; 1.4 us a step).
+  constexpr bool RESW = H == 64;
+  static_assert(!(RESW && PL), "the plane stores ride in the streamed k-steps");
+  u32x4 wr[RESW ? 4 * KS : 1][UT];
+  if constexpr (RESW) {
+#pragma unroll
+    for (int f = 0; f < 4 * KS; ++f)
+#pragma unroll
+      for (int i = 0; i < UT; ++i) wr[f][i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(f * UT + i) * 1024 + voff);
+  }
   // every lane re-reads from LDS only what it wrote itself, so no barrier is needed
 #pragma unroll 1
-  for (int n = 0; n < KS / 2; ++n) {
+  for (int n = 0; n < (RESW ? 0 : KS / 2); ++n) {
     const u32x4* src = reinterpret_cast<const u32x4*>(hu_ptr(2 * n + 1, 3)) + lane;
 #pragma unroll
     for (int i = 0; i < UT; ++i) wlds[(n * UT + i) * (C::NW * 64) + tid] = src[i * 64];
@@ -168,9 +179,11 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
   u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
 #pragma unroll
   for (int i = 0; i < UT; ++i) w0[i] = w1[i] = w2[i] = w3[i] = u32x4{0u, 0u, 0u, 0u};
-  w_issue<UT>(w0, hu_ptr(0, 0), voff);
-  w_issue<UT>(w1, hu_ptr(0, 1), voff);
-  w_issue<UT>(w2, hu_ptr(0, 2), voff);
+  if constexpr (!RESW) {
+    w_issue<UT>(w0, hu_ptr(0, 0), voff);
+    w_issue<UT>(w1, hu_ptr(0, 1), voff);
+    w_issue<UT>(w2, hu_ptr(0, 2), voff);
+  }
 
   // byte offset of this lane's A fragment (row r, chunk 4*ks + g) inside a plane
   auto a_off = [&](int ks) { return r * (H * 2) + (((4 * ks + g) ^ (r & R::SWZ_F)) << 4); };
@@ -238,10 +251,24 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
         ah = nh;
         al = nl;
       };
+      if constexpr (RESW) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kn = (ks + 1) & (KS - 1);
+          const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);
+          mma_hi(wr[ks * 4 + 0], 0);
+          mma_hi(wr[ks * 4 + 1], 1);
+          mma_lo(wr[ks * 4 + 2], 0);
+          mma_lo(wr[ks * 4 + 3], 1);
+          ah = nh;
+          al = nl;
+        }
+      } else {
 #pragma unroll 1
-      for (int ks = 0; ks < KS; ks += 2) {
-        kstep(ks, std::false_type{});
-        kstep(ks + 1, std::true_type{});
+        for (int ks = 0; ks < KS; ks += 2) {
+          kstep(ks, std::false_type{});
+          kstep(ks + 1, std::true_type{});
+        }
       }
     }
 
@@ -288,9 +315,11 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_fwd_kernel(
   // The ring wrapped into a step that does not exist.  Waiting on the buffers here keeps them live
   // to the end: were they dead after their last MFMA, the allocator would reuse registers that
   // these loads still write to.
-  w_wait<0, UT>(w0);
-  w_wait<0, UT>(w1);
-  w_wait<0, UT>(w2);
+  if constexpr (!RESW) {
+    w_wait<0, UT>(w0);
+    w_wait<0, UT>(w1);
+    w_wait<0, UT>(w2);
+  }
   if (PL) {   // h_{T-1}: no product reads it, copy its tiles out of LDS (the barrier that ended the last step covers it)
     const unsigned char* hl = smem3 + (T & 1) * (2 * PLANE);
     char* hp_t = hp.base + hp.tile(bt, T - 1, 0, 0);
@@ -380,10 +409,21 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
   u32x4 w0[UT], w1[UT], w2[UT], w3[UT];
 #pragma unroll
   for (int i = 0; i < UT; ++i) w0[i] = w1[i] = w2[i] = w3[i] = u32x4{0u, 0u, 0u, 0u};
-  // the whole ring lives in AGPRs: the cell backward needs the arch VGPRs for its VALU operands
-  w_issue<UT, RING_AG>(w0, ks_ptr(0), voff);
-  w_issue<UT, RING_AG>(w1, ks_ptr(1), voff);
-  w_issue<UT, RING_AG>(w2, ks_ptr(2), voff);
+  // hidden 64: the wave's share of the image (16 fragments) stays in registers, as in the forward kernel
+  constexpr bool RESW = H == 64;
+  static_assert(!(RESW && PL), "the plane stores ride in the streamed k-steps");
+  u32x4 wr[RESW ? KS : 1][UT];
+  if constexpr (RESW) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < UT; ++i) wr[ks][i] = *reinterpret_cast<const u32x4*>(ks_ptr(ks) + (size_t)i * 1024 + voff);
+  } else {
+    // the whole ring lives in AGPRs: the cell backward needs the arch VGPRs for its VALU operands
+    w_issue<UT, RING_AG>(w0, ks_ptr(0), voff);
+    w_issue<UT, RING_AG>(w1, ks_ptr(1), voff);
+    w_issue<UT, RING_AG>(w2, ks_ptr(2), voff);
+  }
 
   // gate gradients of step t from the running dh / dc: dA to LDS (bf16 planes, buffer t & 1) and
   // to the gates buffer, bias-gradient partial sums in registers
@@ -488,6 +528,26 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
     // loads - a whole HBM latency - and the cell backward's stores before the product's first MFMA.
     constexpr std::integral_constant<int, 3 * UT> steady{};
     constexpr std::integral_constant<int, 5 * UT> first{};
+    if constexpr (RESW) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kn = (ks + 1) & (KS - 1);
+        const u32x4 nh = lds_a(0, kn), nl = lds_a(1, kn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jl = 0; jl < JPW; ++jl)
+          acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), as_bf16x8(wr[ks][jl]), acc[jl], 0, 0, 0);
+#pragma unroll
+        for (int jl = 0; jl < JPW; ++jl)
+          acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(wr[ks][JPW + jl]), acc[jl], 0, 0, 0);
+#pragma unroll
+        for (int jl = 0; jl < JPW; ++jl)
+          acc[jl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(wr[ks][jl]), acc[jl], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ah = nh;
+        al = nl;
+      }
+    } else {
     w_issue<UT, RING_AG>(w3, ks_ptr(3), voff);
     kstep(w0, 0, first);
     w_issue<UT, RING_AG>(w0, ks_ptr(4 & (KS - 1)), voff);
@@ -507,14 +567,17 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec3_bwd_kernel(
       w_issue<UT, RING_AG>(w2, ks_ptr((ks + 6) & (KS - 1)), voff);
       kstep(w3, ks + 3, steady);
     }
+    }
 #pragma unroll
     for (int jl = 0; jl < JPW; ++jl) dh[jl] = acc[jl];
     cell_bwd(t);
   }
   // keep the wrapped-around ring loads' registers live until they have landed (see the forward kernel)
-  w_wait<0, UT, RING_AG>(w0);
-  w_wait<0, UT, RING_AG>(w1);
-  w_wait<0, UT, RING_AG>(w2);
+  if constexpr (!RESW) {
+    w_wait<0, UT, RING_AG>(w0);
+    w_wait<0, UT, RING_AG>(w1);
+    w_wait<0, UT, RING_AG>(w2);
+  }
   if (PL) {   // dA_0: no product reads it, copy its tiles out of LDS
     lds_barrier();
     const unsigned char* da_s = smem3;   // buffer 0 & 1

@@ -421,12 +421,13 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
   }
 }
 
-// out[n] (+)= sum_p part[p * pitch + n].  One workgroup per 64 columns; its 16 waves split the
+// out[n] (+)= sum_p part[p * pitch + n], and the same into out2 when given (the two bias gradients of an LSTM layer
+// are the same sums).  One workgroup per 64 columns; its 16 waves split the
 // partials (coalesced 256-byte rows, four loads in flight per wave) and combine through LDS in a
 // fixed order (deterministic).
 __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part,
-                                                               float* __restrict__ out, int nparts, int N,
-                                                               long pitch, int accumulate) {
+                                                               float* __restrict__ out, float* __restrict__ out2,
+                                                               int nparts, int N, long pitch, int accumulate) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
 #pragma unroll
     for (int w = 0; w < 16; ++w) tot += red[w][lane];
     out[n] = accumulate ? out[n] + tot : tot;
+    if (out2 != nullptr) out2[n] = accumulate ? out2[n] + tot : tot;
   }
 }
 
@@ -516,10 +518,15 @@ int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const floa
   return VTS_ERR_UNSUPPORTED;
 }
 
-int vts_colsum_partials(const float* part, float* out, int nparts, int N, long pitch, int accumulate,
-                        hipStream_t stream) {
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(vts_cdiv(N, 64)), dim3(1024), 0, stream, part, out, nparts, N,
+int vts_colsum_partials2(const float* part, float* out, float* out2, int nparts, int N, long pitch, int accumulate,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(vts_cdiv(N, 64)), dim3(1024), 0, stream, part, out, out2, nparts, N,
                      pitch, accumulate);
   VTS_CHECK_LAUNCH("colsum_partials");
   return VTS_OK;
+}
+
+int vts_colsum_partials(const float* part, float* out, int nparts, int N, long pitch, int accumulate,
+                        hipStream_t stream) {
+  return vts_colsum_partials2(part, out, nullptr, nparts, N, pitch, accumulate, stream);
 }

@@ -100,6 +100,8 @@ int vts_lstm_rec_fwd(float* G, float* cseq, float* hseq, float* hlast, float* cl
                      int H, hipStream_t stream);
 int vts_lstm_rec_bwd(float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
                      float* dbpart, const float* W_hh, float* Wp, int B, int T, int H, hipStream_t stream);
+int vts_colsum_partials2(const float* part, float* out, float* out2, int nparts, int N, long pitch, int accumulate,
+                         hipStream_t stream);
 int vts_colsum_partials(const float* part, float* out, int nparts, int N, long pitch, int accumulate,
                         hipStream_t stream);
 int vts_ew_reparam_fwd(int mode, const float* mean, const float* logvar, const float* scale, const float* shape,
@@ -398,8 +400,9 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
     VTS_REQUIRE(!dg_planes, "lstm_recurrent_bwd: plane output needs dtype_mode 1 and a hidden size of 256");
     VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
   }
-  if (db_ih) VTS_RC(vts_colsum_partials(dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));
-  if (db_hh) VTS_RC(vts_colsum_partials(dbpart, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
+  if (db_ih && db_hh && db_ih != db_hh) VTS_RC(vts_colsum_partials2(dbpart, db_ih, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
+  else if (db_ih) VTS_RC(vts_colsum_partials(dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));
+  else if (db_hh) VTS_RC(vts_colsum_partials(dbpart, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
   return VTS_OK;
 }
 
