@@ -762,12 +762,19 @@ def main():
         # (resident: the share of the image a workgroup keeps on chip - an eighth in LDS forward; backward an eighth
         # in registers, in the hidden-256 bf16x3 kernel only)
         bwd_resident = 0.125 if (a.mode == "bf16x3" and a.H == 256 and os.environ.get("VTS_LSTM_STAGED_BWD", "1")[:1] != "0") else 0.0
+        pair_bwd = (a.mode == "bf16x3" and a.H == 256 and a.batch % 32 == 0 and a.batch // 16 <= 256
+                    and os.environ.get("VTS_LSTM_PAIR_BWD", "1")[:1] != "0" and os.environ.get("VTS_LSTM_CLUSTER_BWD", "0")[:1] != "1")
         for name, resident in (("lstm_recurrent_fwd", 0.125 if a.H >= 128 else 0.0), ("lstm_recurrent_bwd", bwd_resident)):
             if name in kernels:
                 nwg = (a.batch + 15) // 16
                 byts = (a.T - 1) * nwg * 4.0 * a.H * a.H * 4 * (1.0 - resident)
                 if name == "lstm_recurrent_fwd" and cluster_fwd:
                     byts = (a.T - 1) * nwg * (128.0 + 16.0) * 1024
+                # (The backward pair kernel - bf16x3, hidden 256, batch a multiple of 32, at most one workgroup per CU -
+                # has one workgroup per 16 windows as well, but a member streams only its half of the image, a
+                # quarter of that half resident in registers, and the members swap 16 KiB of partial sums a step.)
+                if name == "lstm_recurrent_bwd" and pair_bwd:
+                    byts = (a.T - 1) * nwg * (0.75 * 512.0 + 2 * 16.0) * 1024
                 gbps = byts / (kernels[name]["avg_ms"] * 1e-3) / 1e9
                 l2[name] = {"bytes_per_launch": byts, "achieved_GBps": round(gbps, 1),
                             "frac_of_l2_peak": round(gbps / PEAK_L2_GBPS, 4)}
@@ -791,7 +798,8 @@ def main():
             "roofline": roofline,
             "recurrent_l2_stream": {"peak_GBps": PEAK_L2_GBPS, "kernels": l2,
                                     "note": "W_hh image re-read from the XCD L2 by every workgroup every step "
-                                            "(forward cluster kernel: h exchange through the L2 instead)"},
+                                            "(forward cluster kernel: h exchange through the L2 instead; backward pair "
+                                            "kernel: half the image per workgroup, three quarters of it streamed)"},
             "step_mfma": {"algorithmic_tflop_per_step": round(total_flops / 1e12, 4),
                           "achieved_tflops": round(total_flops / (ms_per_step * 1e-3) / 1e12, 2),
                           "executed_tflops": round(exec_mult * total_flops / (ms_per_step * 1e-3) / 1e12, 2),
