@@ -252,7 +252,7 @@ def test_linear_strided_input():
     assert l2_rel(y, seq[:, -1, :] @ w.t()) < 1e-5
 
 
-@pytest.mark.parametrize("M,H", [(16, 64), (37, 256), (1000, 16)])
+@pytest.mark.parametrize("M,H", [(16, 64), (37, 256), (1000, 16), (530, 128), (4096, 256)])
 def test_layer_norm(M, H):
     import vts
     dev = _dev()

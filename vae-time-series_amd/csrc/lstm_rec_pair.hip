@@ -17,6 +17,12 @@
 // (Measured alternatives for two members that share an L2: plain stores change nothing - the sc1 read is the
 // slow part, about 3 000 clocks; a plain read behind `buffer_inv sc1` drops the W_hh image from the L2 and doubles
 // the step; behind `buffer_inv sc0` it returns stale lines of the L1.)
+// Where the slots live.  Agent-scope (sc1) stores are written through the L2 to memory and sc1 reads of such lines
+// come back from there: 1.2 GB of HBM traffic per launch at 4096 windows, a third on top of what the kernel must
+// move.  Two members that share an L2 need none of it - a plain store stops in the L2, where the peer's sc1 read
+// (which only goes around its own L1) finds it.  Workgroup b is expected on XCD b mod 8, which puts a pair on one
+// XCD, but nothing guarantees it; so the members first tell each other where they run (the XCC_ID hardware register,
+// exchanged with sc1 accesses) and use plain stores only if the two values are equal, sc1 stores otherwise.
 // Three slots in rotation: between a reset and the producer's next store into the same slot lie a full drain of the
 // consumer's memory operations (the wait of the next step's read) and two hand-offs, so the reset cannot overtake it.
 // Reads are bounded: when the peer never shows up the wave goes on with NaN and sets the launch's status word.
@@ -48,8 +54,10 @@ constexpr int STG = 6 * NI * 1024;            // staging bytes per wave
 constexpr int P_LDS = DA_LDS + 4 * STG;       // 160 KiB
 constexpr int XW = NI * 1024;                 // bytes one wave publishes per step
 constexpr int XSLOTS = 3;
-constexpr int X_PAIR = XSLOTS * 2 * 4 * XW;   // [slot][destination member][wave] = 96 KiB per pair
+constexpr int X_SLOTS_B = XSLOTS * 2 * 4 * XW;   // [slot][destination member][wave] = 96 KiB per pair
+constexpr int X_PAIR = X_SLOTS_B + 256;       // ... and, behind them, one word per member: where it runs (below)
 constexpr unsigned EMPTY = 0xffffffffu;
+constexpr int SC1 = 16;                       // cache-policy operand of the buffer builtins: agent scope
 typedef unsigned pvec4 __attribute__((vector_size(16)));
 __device__ __forceinline__ bf16x8 pfrag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -139,6 +147,27 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
                        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xbase >> 32)) & 0xffffu, (unsigned)X_PAIR,
                        0x00020000u};
   bool dead = false;
+  // Do the members share an L2?  Every wave asks for itself (no barrier, no LDS): lane 0's value counts.
+  bool same_l2;
+  {
+    unsigned here;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(here));
+    here = (here & 0x00ffffffu) | 0x01000000u;                      // never EMPTY
+    const int hs = X_SLOTS_B + wave * 16;                           // [wave][member] words
+    if (lane == 0 && m != mute_member) __builtin_amdgcn_raw_buffer_store_b32(here, xrsrc, hs + m * 4, 0, SC1);
+    unsigned peer = EMPTY;
+    for (int spins = 0; spins < spin_limit; ++spins) {
+      peer = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, hs + (1 - m) * 4, 0, SC1);
+      peer = __builtin_amdgcn_readfirstlane(peer);
+      if (peer != EMPTY) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (peer == EMPTY) {
+      if (lane == 0) atomicOr(err, 2u);
+      dead = true;
+    }
+    same_l2 = peer == here;
+  }
 
   // LDS traffic of this wave done, then the barrier (no fence: a fence would wait for the ring and the batch)
   auto wg_barrier = [] {
@@ -379,8 +408,10 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     const int xs = slot * (2 * 4 * XW);
     if (m != mute_member) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pvec4, acc[i]), xrsrc, xs + tx0 + i * 1024, 0, 16);
+      for (int i = 0; i < NI; ++i) {
+        if (same_l2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pvec4, acc[i]), xrsrc, xs + tx0 + i * 1024, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pvec4, acc[i]), xrsrc, xs + tx0 + i * 1024, 0, SC1);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(3);
@@ -393,7 +424,7 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     pvec4 pay[NI];
     auto load_pay = [&] {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) pay[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xs + rx0 + i * 1024, 0, 16);
+      for (int i = 0; i < NI; ++i) pay[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xs + rx0 + i * 1024, 0, SC1);
     };
     auto ask_peer = [&](auto after) {
       if constexpr (decltype(after)::value == PAY_AT) {
@@ -468,8 +499,10 @@ __global__ __launch_bounds__(256) void lstm_rec3p_bwd_kernel(
     // a write-through round trip.  A wave that gave up resets too: it no longer matters.)
     asm volatile("" : "+v"(dh[0]), "+v"(dh[1]), "+v"(dh[2]), "+v"(dh[3]) :: "memory");
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_buffer_store_b128(pvec4{EMPTY, EMPTY, EMPTY, EMPTY}, xrsrc, xs + rx0 + i * 1024, 0, 16);
+    for (int i = 0; i < NI; ++i) {
+      if (same_l2) __builtin_amdgcn_raw_buffer_store_b128(pvec4{EMPTY, EMPTY, EMPTY, EMPTY}, xrsrc, xs + rx0 + i * 1024, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(pvec4{EMPTY, EMPTY, EMPTY, EMPTY}, xrsrc, xs + rx0 + i * 1024, 0, SC1);
+    }
     slot = slot == XSLOTS - 1 ? 0 : slot + 1;
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(11);
