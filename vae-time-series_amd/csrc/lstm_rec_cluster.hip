@@ -351,6 +351,8 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
         const u32x4 v = *reinterpret_cast<const u32x4*>(stage + p * S_PLANE + (rt * 16 + (l & 15)) * 64 + (l >> 4) * 16);
         const int off = planes ? hp_block(rt, t, c, p) + gp::slot(l >> 4, l & 15) * 16
                                : xout_off + p * X_PLANE + (rt * KS + c) * 1024 + l * 16;
+        // (sc1 although the members of a cluster share an L2 when dispatch is round-robin: plain stores here
+        // measured 10 % slower per launch and moved the same bytes)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, v), xrsrc, off, 0, 16);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
