@@ -56,7 +56,9 @@ __device__ __forceinline__ float lane_xor1(float v) {
 
 // image for this kernel: [member c][ks][hi | lo][ct = gate*2 + jl][lane] ->
 //   W_hh[gate*H + (2c + jl)*16 + (lane & 15)][32*ks + 8*(lane >> 4) + e],  e = 0..7
-__global__ void pack_whh3c_kernel(const float* __restrict__ W, u32x4* __restrict__ out) {
+__global__ void pack_whh3c_kernel(const float* __restrict__ W, u32x4* __restrict__ out, void* handoff, long n16,
+                                  unsigned* status) {
+  reset_handoff(handoff, n16, 0u, status);
   const int total = CH * CH;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63;
@@ -414,7 +416,9 @@ constexpr int SB_WAVE = 4 * 1024;                      // per-wave staging: 16 w
 constexpr int CB_LDS = WB_LDS + 4 * SB_WAVE;           // 144 KiB
 
 // image: [member c][ks][hi | lo][ct][lane] -> W_hh[gate_major(k')][(2c + ct)*16 + (lane & 15)], k' = 32 ks + 8 (lane >> 4) + e
-__global__ void pack_whh3cb_kernel(const float* __restrict__ W, u32x4* __restrict__ out) {
+__global__ void pack_whh3cb_kernel(const float* __restrict__ W, u32x4* __restrict__ out, void* handoff, long n16,
+                                  unsigned* status) {
+  reset_handoff(handoff, n16, 0u, status);
   const int total = CH * CH;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63;
@@ -724,13 +728,15 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
     }
   }
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
-  hipLaunchKernelGGL(pack_whh3c_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img);
-  VTS_CHECK_LAUNCH("pack_whh3c");
+  // (the packing kernel also zeroes the hand-off flags and the launch's status word)
   unsigned* flags = reinterpret_cast<unsigned*>(fws);
-  if (hipMemsetAsync(flags, 0, vts_lstm_rec3c_flag_bytes(B), stream) != hipSuccess) {
-    vts_set_error("lstm_rec3c_fwd: clearing the hand-off flags failed");
-    return VTS_ERR_HIP;
+  if (!vts_aligned16(fws)) {
+    vts_set_error("lstm_rec3c_fwd: the flag words must be 16-byte aligned");
+    return VTS_ERR_ARG;
   }
+  hipLaunchKernelGGL(pack_whh3c_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img, fws,
+                     (long)(vts_lstm_rec3c_flag_bytes(B) / 16), err);
+  VTS_CHECK_LAUNCH("pack_whh3c");
   // polls give up after about two seconds (1024 rounds under the test hook above)
   int mute_member = g_fault_member.load();
   int spin_limit = mute_member >= 0 ? 1 << 10 : 1 << 21;
@@ -778,13 +784,14 @@ int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, co
     return VTS_ERR_UNSUPPORTED;
   }
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
-  hipLaunchKernelGGL(pack_whh3cb_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img);
-  VTS_CHECK_LAUNCH("pack_whh3cb");
   unsigned* flags = reinterpret_cast<unsigned*>(fws);
-  if (hipMemsetAsync(flags, 0, vts_lstm_rec3c_bwd_flag_bytes(B), stream) != hipSuccess) {
-    vts_set_error("lstm_rec3c_bwd: clearing the hand-off flags failed");
-    return VTS_ERR_HIP;
+  if (!vts_aligned16(fws)) {
+    vts_set_error("lstm_rec3c_bwd: the flag words must be 16-byte aligned");
+    return VTS_ERR_ARG;
   }
+  hipLaunchKernelGGL(pack_whh3cb_kernel, dim3(vts_cdiv(CH * CH, 256)), dim3(256), 0, stream, W_hh, img, fws,
+                     (long)(vts_lstm_rec3c_bwd_flag_bytes(B) / 16), err);
+  VTS_CHECK_LAUNCH("pack_whh3cb");
   int mute_member = g_fault_member.load();
   int spin_limit = mute_member >= 0 ? 1 << 10 : 1 << 21;
   int nc = nclusters;

@@ -13,6 +13,16 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Tail of the weight-packing kernels of the cluster and pair recurrences: the launch's hand-off words (n16 pieces of
+// 16 bytes) set to `pattern` and its status word cleared, so that no memset launch stands in front of the recurrence.
+__device__ __forceinline__ void reset_handoff(void* words, long n16, unsigned pattern, unsigned* status) {
+  typedef unsigned rh4 __attribute__((ext_vector_type(4)));
+  rh4* p = reinterpret_cast<rh4*>(words);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x)
+    p[i] = rh4{pattern, pattern, pattern, pattern};
+  if (status != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *status = 0u;
+}
+
 template <int H>
 struct RecCfg {
   static constexpr int JT = H / 16;                 // hidden tiles

@@ -65,7 +65,9 @@ __device__ __forceinline__ bf16x8 pfrag(u32x4 v) { return __builtin_bit_cast(bf1
 //   W_hh[(k' & 3) * H + (k' >> 2)][nt * 16 + (lane & 15)],  k' = 512 m + 32 ks + 8 (lane >> 4) + e (e = 0..7: the
 //   column order 4 * hidden + gate in which the cell phase writes dA), ks = 2 (u & 7) + kl,
 //   nt = 8 (u < 8 ? 1 - m : m) + 2 w + jl
-__global__ void pack_whh3p_kernel(const float* __restrict__ W, u32x4* __restrict__ out) {
+__global__ void pack_whh3p_kernel(const float* __restrict__ W, u32x4* __restrict__ out, void* handoff, long n16,
+                                  unsigned* status) {
+  reset_handoff(handoff, n16, EMPTY, status);
   const int total = PH * PH;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63;
@@ -585,12 +587,14 @@ int vts_lstm_rec3p_bwd(const float* G, const float* cseq, const float* dhseq, co
     return VTS_ERR_UNSUPPORTED;
   }
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
-  hipLaunchKernelGGL(pack_whh3p_kernel, dim3(vts_cdiv(PH * PH, 256)), dim3(256), 0, stream, W_hh, img);
-  VTS_CHECK_LAUNCH("pack_whh3p");
-  if (hipMemsetAsync(xws, 0xff, vts_lstm_rec3p_xchg_bytes(B), stream) != hipSuccess) {
-    vts_set_error("lstm_rec3p_bwd: clearing the exchange buffer failed");
-    return VTS_ERR_HIP;
+  // (the packing kernel also sets every word of the exchange buffer to EMPTY and clears the launch's status word)
+  if (!vts_aligned16(xws)) {
+    vts_set_error("lstm_rec3p_bwd: the exchange buffer must be 16-byte aligned");
+    return VTS_ERR_ARG;
   }
+  hipLaunchKernelGGL(pack_whh3p_kernel, dim3(vts_cdiv(PH * PH, 256)), dim3(256), 0, stream, W_hh, img, xws,
+                     (long)(vts_lstm_rec3p_xchg_bytes(B) / 16), err);
+  VTS_CHECK_LAUNCH("pack_whh3p");
   int mute_member = g_pair_fault.load();
   int spin_limit = mute_member >= 0 ? 1 << 10 : 1 << 20;
   int np = npairs;

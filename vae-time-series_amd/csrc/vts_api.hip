@@ -281,12 +281,9 @@ static int recurrent_fwd_impl(float* gates, float* cells, float* hseq, float* h_
   // live in the parts of the workspace that only the backward pass uses (gradient seeds, bias partials), which
   // are exactly large enough: 2 KiB and 256 B per window against 2 KiB and ~8 B needed.
   static const bool cluster_on = [] { const char* e = getenv("VTS_LSTM_CLUSTER"); return !(e && e[0] == '0'); }();
-  // status word of this launch (vts_lstm_recurrent_fwd_status): only the cluster kernel can set it
+  // status word of this launch (vts_lstm_recurrent_fwd_status): only the cluster kernel can set it (its packing
+  // kernel clears it; the other kernels' launches clear it here)
   unsigned* status = rec_ws_status(workspace, B, H);
-  if (hipMemsetAsync(status, 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
-    vts_set_error("lstm_recurrent_fwd: clearing the status word failed");
-    return VTS_ERR_HIP;
-  }
   if (dtype_mode == 1 && cluster_on && vts_lstm_rec3c_usable((int)B, (int)T, (int)H)) {
     char* ws = reinterpret_cast<char*>(workspace);
     char* fws = ws + rec_ws_pack_bytes(H);
@@ -295,6 +292,10 @@ static int recurrent_fwd_impl(float* gates, float* cells, float* hseq, float* h_
                                       status, (int)B, (int)T, h_planes, reinterpret_cast<hipStream_t>(stream));
     // the runtime would not guarantee a resident grid: nothing was launched, take the one-workgroup kernel
     if (rc != VTS_ERR_UNSUPPORTED) return rc;
+  }
+  if (hipMemsetAsync(status, 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+    vts_set_error("lstm_recurrent_fwd: clearing the status word failed");
+    return VTS_ERR_HIP;
   }
   // bf16x3 recurrence for the hidden sizes it is built for; smaller ones stay on the fp32 kernel
   if (dtype_mode == 1 && vts_lstm_rec3_supported((int)H))
@@ -374,11 +375,7 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
     // (lstm_rec_pair.hip; VTS_LSTM_PAIR_BWD=0 at start-up or vts_debug_set_pair_bwd(0) turns it off)
     if (dg_planes && g_pair_bwd.load() > 0 && g_cluster_bwd.load() == 0 && rec_ws_pair_bytes(B, H) > 0 &&
         vts_lstm_rec3p_usable((int)B, (int)T, (int)H)) {
-      unsigned* status = rec_ws_status(workspace, B, H);
-      if (hipMemsetAsync(status, 0, sizeof(unsigned), st) != hipSuccess) {
-        vts_set_error("lstm_recurrent_bwd: clearing the status word failed");
-        return VTS_ERR_HIP;
-      }
+      unsigned* status = rec_ws_status(workspace, B, H);       // (cleared by the kernel that packs W_hh)
       rc = vts_lstm_rec3p_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, dg_planes,
                               reinterpret_cast<char*>(status) + 256 + rec_ws_bflag_bytes(B), status, (int)B, (int)T, st);
       if (rc != VTS_OK && rc != VTS_ERR_UNSUPPORTED) return rc;
