@@ -219,11 +219,14 @@ class _LSTMLayer(torch.autograd.Function):
         return gin, dw_ih, dw_hh, db_ih, db_hh, None
 
 
-def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int, need_output: bool = True
-         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int, need_output: bool = True,
+         top_state_only: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(output, h_n, c_n) of a stacked batch-first LSTM; ``weights`` = [w_ih, w_hh, b_ih, b_hh] per layer.
     need_output=False (callers that read only h_n, as the reference's encoders do: gaussian-lstm-DE.py:28) lets
-    the plane path skip the fp32 copy of the top layer's sequence; ``output`` is then an empty tensor."""
+    the plane path skip the fp32 copy of the top layer's sequence; ``output`` is then an empty tensor.
+    top_state_only=True (the same callers: they read h_n[-1]) returns h_n and c_n as [1, B, H] views of the top
+    layer's final state instead of stacking every layer's: no copy kernels forward, and backward the lower
+    layers get no state gradient at all rather than a block of zeros to convert."""
     _need_gpu(x)
     lib = L.load()
     x = x.contiguous()
@@ -237,6 +240,8 @@ def lstm(x: torch.Tensor, weights: Sequence[torch.Tensor], num_layers: int, need
         act, h_last, c_last = _LSTMLayer.apply(act, *weights[4 * k:4 * k + 4], cfg)
         hs.append(h_last)
         cs.append(c_last)
+    if top_state_only:
+        return act, hs[-1].unsqueeze(0), cs[-1].unsqueeze(0)
     return act, torch.stack(hs), torch.stack(cs)
 
 

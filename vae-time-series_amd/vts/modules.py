@@ -55,17 +55,18 @@ class LSTM(nn.Module):
                     getattr(self, f"bias_ih_l{k}"), getattr(self, f"bias_hh_l{k}")]
         return out
 
-    def forward(self, x: torch.Tensor, hx=None, need_output: bool = True):
+    def forward(self, x: torch.Tensor, hx=None, need_output: bool = True, top_state_only: bool = False):
         """As nn.LSTM.forward.  need_output=False: the caller reads only (h_n, c_n) - the reference's encoders
         do, e.g. gaussian-lstm-DE.py:28 - and `output` comes back as an empty tensor (saves writing the top
-        layer's fp32 sequence on the bench-sized path)."""
+        layer's fp32 sequence on the bench-sized path).  top_state_only=True: the caller reads only h_n[-1] /
+        c_n[-1]; both come back as [1, B, H] (the top layer's final state) without stacking the other layers'."""
         if hx is not None:
             raise NotImplementedError("vts.LSTM: a non-zero initial state is not supported")
         if isinstance(x, nn.utils.rnn.PackedSequence):
             raise NotImplementedError("vts.LSTM: packed sequences are not supported")
         if x.dim() != 3 or x.shape[2] != self.input_size:
             raise ValueError(f"vts.LSTM: expected input [B, T, {self.input_size}], got {tuple(x.shape)}")
-        out, h_n, c_n = F.lstm(x, self.flat_weights(), self.num_layers, need_output)
+        out, h_n, c_n = F.lstm(x, self.flat_weights(), self.num_layers, need_output, top_state_only)
         return out, (h_n, c_n)
 
 
@@ -87,7 +88,8 @@ def _keep_mask(noise: Noise, key: str, training: bool, shape, device) -> Optiona
         return noise[key]
     if not training:
         return None
-    return (torch.rand(shape, device=device) >= F.DROP_P).float()
+    # one launch (uniform draw, compare and conversion in the generator kernel): keep with probability 1 - p
+    return torch.empty(shape, device=device).bernoulli_(1.0 - F.DROP_P)
 
 
 # ------------------------------------------------------------------------------ Gaussian VAE
@@ -99,7 +101,7 @@ class GaussianEncoder(nn.Module):
         self.logvar_layer = Linear(lstm_output_dim, latent_dim)
 
     def forward(self, x):
-        _, (h_n, _) = self.lstm(x, need_output=False)
+        _, (h_n, _) = self.lstm(x, need_output=False, top_state_only=True)
         h = h_n[-1]
         heads = [(self.mean_layer.weight, self.mean_layer.bias, L.ACT_NONE),
                  (self.logvar_layer.weight, self.logvar_layer.bias, L.ACT_NONE)]
@@ -166,7 +168,7 @@ class DeepEncoder(nn.Module):
         self.gaussian_heads = gaussian_heads
 
     def forward(self, x, noise: Noise = None):
-        _, (h_n, _) = self.lstm(x, need_output=False)
+        _, (h_n, _) = self.lstm(x, need_output=False, top_state_only=True)
         h = self.layer_norm(h_n[-1])
         keep = _keep_mask(noise, "enc_keep", self.training, (h.shape[0], 64), h.device)
         trunk = [(self.fc1.weight, self.fc1.bias, L.ACT_RELU), (self.fc2.weight, self.fc2.bias, L.ACT_RELU_DROPOUT)]
@@ -275,7 +277,7 @@ class ThreeComponentEncoder(DeepEncoder):
         self.logits_layer_zero = Linear(64, latent_dim)
 
     def forward(self, x, noise: Noise = None):
-        _, (h_n, _) = self.lstm(x, need_output=False)
+        _, (h_n, _) = self.lstm(x, need_output=False, top_state_only=True)
         h = self.layer_norm(h_n[-1])
         keep = _keep_mask(noise, "enc_keep", self.training, (h.shape[0], 64), h.device)
         trunk = [(self.fc1.weight, self.fc1.bias, L.ACT_RELU), (self.fc2.weight, self.fc2.bias, L.ACT_RELU_DROPOUT)]
