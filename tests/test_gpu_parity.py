@@ -174,6 +174,29 @@ def test_lstm_matches_oracle(B, T, C, H, layers, mode):
         assert l2_rel(p.grad, getattr(ref, k).grad) < TOL, k
 
 
+@pytest.mark.parametrize("B,T,C,H", [(16, 16, 1, 64), (128, 6, 16, 256)])
+@pytest.mark.parametrize("mode", MODES, indirect=True)
+def test_lstm_top_state_only(B, T, C, H, mode):
+    """top_state_only=True hands back the top layer's final state alone; a loss on it gives every parameter the
+    gradient it gets through the stacked h_n[-1] (the lower layers then receive no state gradient at all)."""
+    import vts
+    dev = _dev()
+    torch.manual_seed(B + H)
+    lstm = vts.LSTM(C, H, num_layers=3).to(dev)
+    x = torch.randn(B, T, C, device=dev)
+    w = torch.randn(H, device=dev)
+    _, (h_full, c_full) = lstm(x, need_output=False)
+    (h_full[-1] * w).sum().backward()
+    ref = [p.grad.clone() for p in lstm.parameters()]
+    lstm.zero_grad()
+    _, (h_top, c_top) = lstm(x, need_output=False, top_state_only=True)
+    assert h_top.shape == (1, B, H) and c_top.shape == (1, B, H)
+    assert torch.equal(h_top[-1], h_full[-1]) and torch.equal(c_top[-1], c_full[-1])
+    (h_top[-1] * w).sum().backward()
+    for p, r in zip(lstm.parameters(), ref):
+        assert l2_rel(p.grad, r) < 1e-6
+
+
 @pytest.mark.parametrize("mode", MODES, indirect=True)
 def test_lstm_input_gradient(mode):
     import vts
