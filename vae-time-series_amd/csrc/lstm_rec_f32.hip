@@ -118,10 +118,14 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
   // weights do not change with t), so ~48 KiB per wave stay in flight to cover the L2 latency.
   constexpr bool RING = (C::KQ_F % 4 == 0);
   f32x4 w0[NT], w1[NT], w2[NT], w3[NT];
+  // Four k-quads in all (hidden 64): the four ring buffers hold the wave's whole share of the image, which is
+  // loaded once - re-loading the same fragments every step put an L2 round trip in front of each block of MFMAs.
+  constexpr bool RESW = RING && C::KQ_F == 4;
   if constexpr (RING) {
     load_w(w0, 0);
     load_w(w1, 1);
     load_w(w2, 2);
+    if constexpr (RESW) load_w(w3, 3);
   }
 
   for (int t = 0; t < T; ++t) {
@@ -158,14 +162,16 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_fwd_kernel(
         };
 #pragma unroll 1
         for (int kq = 0; kq < C::KQ_F; kq += 4) {
-          if (NLB > 0 && (kq & 4)) load_w_lds(w3, kq >> 3);   // k-quads 7, 15: LDS-resident
-          else load_w(w3, kq + 3);
+          if constexpr (!RESW) {
+            if (NLB > 0 && (kq & 4)) load_w_lds(w3, kq >> 3);   // k-quads 7, 15: LDS-resident
+            else load_w(w3, kq + 3);
+          }
           block(w0, kq);
-          load_w(w0, (kq + 4) & (C::KQ_F - 1));
+          if constexpr (!RESW) load_w(w0, (kq + 4) & (C::KQ_F - 1));
           block(w1, kq + 1);
-          load_w(w1, (kq + 5) & (C::KQ_F - 1));
+          if constexpr (!RESW) load_w(w1, (kq + 5) & (C::KQ_F - 1));
           block(w2, kq + 2);
-          load_w(w2, (kq + 6) & (C::KQ_F - 1));
+          if constexpr (!RESW) load_w(w2, (kq + 6) & (C::KQ_F - 1));
           block(w3, kq + 3);
         }
       } else if constexpr (C::KQ_F == 1) {
@@ -302,10 +308,12 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
   // W_hh fragment ring, three blocks ahead, wrapping into the next step (see the forward kernel)
   constexpr bool RING = (NBLK % 4 == 0);
   f32x4 w0[KB * JPW], w1[KB * JPW], w2[KB * JPW], w3[KB * JPW];
+  constexpr bool RESW = RING && NBLK == 4;     // hidden 64: the four buffers hold the whole share, loaded once
   if constexpr (RING) {
     load_w(w0, 0);
     load_w(w1, 1);
     load_w(w2, 2);
+    if constexpr (RESW) load_w(w3, 3);
   }
 
   for (int t = T - 1; t >= 0; --t) {
@@ -381,13 +389,13 @@ __global__ __launch_bounds__(RecCfg<H>::NW * 64) void lstm_rec_bwd_kernel(
     if constexpr (RING) {
 #pragma unroll 1
       for (int blk = 0; blk < NBLK; blk += 4) {
-        load_w(w3, blk + 3);
+        if constexpr (!RESW) load_w(w3, blk + 3);
         mma(w0, blk);
-        load_w(w0, (blk + 4) & (NBLK - 1));
+        if constexpr (!RESW) load_w(w0, (blk + 4) & (NBLK - 1));
         mma(w1, blk + 1);
-        load_w(w1, (blk + 5) & (NBLK - 1));
+        if constexpr (!RESW) load_w(w1, (blk + 5) & (NBLK - 1));
         mma(w2, blk + 2);
-        load_w(w2, (blk + 6) & (NBLK - 1));
+        if constexpr (!RESW) load_w(w2, (blk + 6) & (NBLK - 1));
         mma(w3, blk + 3);
       }
     } else if constexpr (NBLK == 1) {
