@@ -21,6 +21,8 @@ if tm:
                    "loads, the pattern that correction is calibrated for: the plane GEMM micro-benchmark reads 2.42 GB by "
                    "this count against 2.42 GB of operands), mean over the launches of a 3-step run",
            "kernels": tm,
-           "algorithmic_bytes_per_launch": {"lstm_rec3[pc]?_bwd": d["roofline"]["algorithmic_bytes_per_launch"]}}
+           "dominant_kernel": d["roofline"]["kernel"],
+           "algorithmic_bytes_per_launch_of_the_dominant_kernel":
+               d["roofline"].get("algorithmic_bytes_per_launch", d["roofline"].get("hbm_view", {}).get("algorithmic_bytes_per_launch"))}
     json.dump(out, open(os.path.join(P, "r02_pmc_hbm_traffic.json"), "w"), indent=1)
     print("traffic", {k: v["hbm_bytes"] for k, v in tm.items()})
