@@ -68,6 +68,9 @@ def parse():
                          "accumulate); both hold the 1e-4 parity bound.  Heads, cell update and ELBO are f32.")
     ap.add_argument("--exact-loss", action="store_true",
                     help="data-parallel runs: loss of the concatenated batch (one more all-reduce of 8 floats per step)")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the step once as a HIP graph (vts.GraphedTrainStep) and time its replays: for the small "
+                         "shapes whose eager step is bound by the host's launch rate; single process, LSTM models")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="windows in the CPU baseline sample")
     ap.add_argument("--traffic", action="store_true",
@@ -658,18 +661,26 @@ def main():
         dom = max((k for k in pre if k in per), key=lambda k: pre[k][1])
     # a full collection now, so that the interpreter's next generation-2 pass (~30 ms over torch's
     # heap, due once per few hundred steps) does not land inside a ten-step timed region
+    graphed = None
+    if a.graph:
+        if launched or world > 1:
+            raise SystemExit("--graph records a single-process step (no gradient all-reduce inside the graph)")
+        graphed = vts.GraphedTrainStep(model, trainer.opt, x, y)
+        for _ in range(max(a.warmup, 1)):
+            graphed(x, y)
     gc.collect()
     sync()
-    L.timer.only = {dom}
-    L.timer.enabled = True
-    L.timer.reset()
+    if graphed is None:             # (no event brackets inside a replay: the kernel pass below times the dominant one)
+        L.timer.only = {dom}
+        L.timer.enabled = True
+        L.timer.reset()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = trainer.step(x, y)
+        loss = graphed(x, y) if graphed is not None else trainer.step(x, y)
     sync()
     elapsed = time.perf_counter() - t0
     L.timer.enabled = False
-    dom_n, dom_total_ms = L.timer.summary()[dom]
+    dom_n, dom_total_ms = L.timer.summary()[dom] if graphed is None else (0, 0.0)
     if launched:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -714,12 +725,14 @@ def main():
             if name in per:   # MFMA kernels: mean algorithmic FLOPs per launch of this name
                 flops = sum(per[name]) / len(per[name])
                 kernels[name]["tflops"] = round(flops / (avg_ms * 1e-3) / 1e12, 2)
-        # the dominant entry point: its launches inside the timed region
-        dom_avg = dom_total_ms / dom_n
-        kernels[dom] = {"launches_per_step": dom_n // a.steps, "avg_ms": round(dom_avg, 4),
-                        "share_of_step": round(dom_total_ms / a.steps / ms_per_step, 4),
-                        "tflops": round(sum(per[dom]) / len(per[dom]) / (dom_avg * 1e-3) / 1e12, 2),
-                        "measured": "HIP events inside the timed region"}
+        # the dominant entry point: its launches inside the timed region (a recorded step has none: the figures of
+        # the eager kernel pass stand)
+        if dom_n > 0:
+            dom_avg = dom_total_ms / dom_n
+            kernels[dom] = {"launches_per_step": dom_n // a.steps, "avg_ms": round(dom_avg, 4),
+                            "share_of_step": round(dom_total_ms / a.steps / ms_per_step, 4),
+                            "tflops": round(sum(per[dom]) / len(per[dom]) / (dom_avg * 1e-3) / 1e12, 2),
+                            "measured": "HIP events inside the timed region"}
         dom_tflops = kernels[dom]["tflops"]
         # Which roofline bounds the dominant kernel: the larger of its two floors, algorithmic FLOPs (x3 executed
         # bf16 products in bf16x3 mode) / matrix peak and algorithmic HBM bytes / HBM peak.  The fraction
@@ -794,7 +807,8 @@ def main():
                                    f"{a.T} steps x {a.C} channels, hidden {a.H}, latent {a.L}, future_steps 1",
                        "model_kind": a.model, "windows_per_gpu": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "rccl_ranks": world if launched else 0, "gemm_mode": a.mode,
-                       "optimizer": "Adam(lr=1e-3) inside the timed step", "noise": "drawn on device every step"},
+                       "optimizer": "Adam(lr=1e-3) inside the timed step", "noise": "drawn on device every step",
+                       "launch": "one recorded HIP graph per step (vts.GraphedTrainStep)" if a.graph else "eager"},
             "roofline": roofline,
             "recurrent_l2_stream": {"peak_GBps": PEAK_L2_GBPS, "kernels": l2,
                                     "note": "W_hh image re-read from the XCD L2 by every workgroup every step "

@@ -13,7 +13,8 @@ run r02_bench_gaussian_bf16x3.json 200 python bench.py --model gaussian --no-cpu
 run r02_bench_gpd_bf16x3.json 200 python bench.py --model gpd --no-cpu-baseline
 run r02_bench_mixture3_bf16x3.json 200 python bench.py --model mixture3 --no-cpu-baseline
 run r02_bench_transformer_bf16x3.json 300 python bench.py --model transformer --no-cpu-baseline
-for b in 16 4096 65536; do run r02_bench_gpd_hurricane_b$b.json 200 python bench.py --model gpd --shape hurricane --batch $b --steps 20 --warmup 3; done
+for b in 16 4096 65536; do run r02_bench_gpd_hurricane_b$b.json 200 python bench.py --model gpd --shape hurricane --batch $b --steps 50 --warmup 3 --graph; done
+run r02_bench_gpd_hurricane_b4096_eager.json 200 python bench.py --model gpd --shape hurricane --batch 4096 --steps 50 --warmup 3 --no-cpu-baseline
 echo benches done
 rm -rf $O/prof_r02
 # (rocprofv3 may crash while the profiled interpreter exits, after its files are on disk: the statistics file decides)
