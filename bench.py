@@ -45,8 +45,8 @@ PEAK_L2_GBPS = 34500.0          # aggregate XCD-L2 read bandwidth
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="mixture", choices=["gaussian", "gpd", "mixture", "mixture3", "transformer"],
                     help="the three LSTM-VAE families (headline: mixture) or the transformer-encoder mixture VAE")
     ap.add_argument("--d-model", type=int, default=64)
