@@ -798,6 +798,7 @@ def main():
             "value_with_adam": round(value, 1),
             "value_fwd_bwd_elbo": round(world * a.batch * a.steps / elapsed_noupd, 1),
             "ms_per_step_fwd_bwd_elbo": round(1e3 * elapsed_noupd / a.steps, 3),
+            **({"fwd_bwd_elbo_note": "launched one by one (only the full step is recorded as a graph)"} if a.graph else {}),
             "dtype": "f32" if a.mode == "f32" else "bf16x3 (fp32 operands split into two bf16, three bf16 MFMA "
                                                     "products per fp32 product, fp32 accumulate); f32 elsewhere",
             "data": "synthetic",
