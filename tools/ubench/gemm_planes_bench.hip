@@ -11,33 +11,57 @@ void vts_set_error(const char*, ...) {}
 
 namespace {
 
+// What both policies do with the finished accumulators: this workgroup's 256 x 256 tile of its slice's slab.
+struct SlabOut {
+  float* C; int N, tm, tn;
+  __device__ __forceinline__ void store(f32x4 (&acc)[4][8]) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = tm * 256 + (wm * 4 + mt) * 16 + 4 * g + reg;
+          const int col = tn * 256 + (wn * 8 + nt) * 16 + r;
+          C[(long)row * N + col] = acc[mt][nt][reg];
+        }
+  }
+};
 // direct: operand [rows][K] as tiles: tile(rt, s, p) = base + ((s * 2 + p) * ntiles + rt) * 1024
 struct Pol {
   const char* A; const char* B;
   int mt_all, nt_all;   // row tiles of the whole operands
   int m0t, n0t;         // first row tile of this workgroup
-  int s0;               // first k-step of this workgroup
-  __device__ __forceinline__ const char* a_tile(int li, int s) const {
-    return A + ((long)((s0 + s) * 2 + (li & 1)) * mt_all + m0t + (li >> 1)) * gp::TILE_B;
+  int s;                // k-step whose loads are being issued (advance() steps to the first one)
+  SlabOut out;
+  __device__ __forceinline__ void advance() { ++s; }
+  __device__ __forceinline__ const char* a_tile(int li) const {
+    return A + ((long)(s * 2 + (li & 1)) * mt_all + m0t + (li >> 1)) * gp::TILE_B;
   }
-  __device__ __forceinline__ const char* b_tile(int li, int s) const {
-    return B + ((long)((s0 + s) * 2 + (li & 1)) * nt_all + n0t + (li >> 1)) * gp::TILE_B;
+  __device__ __forceinline__ const char* b_tile(int li) const {
+    return B + ((long)(s * 2 + (li & 1)) * nt_all + n0t + (li >> 1)) * gp::TILE_B;
   }
+  __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) { out.store(acc); }
 };
 // transposed: operand [tokens][features] as tiles of 16 tokens x 32 features: tile(tt, cb, p) = base + ((tt * ncb + cb) * 2 + p) * 1024
 struct PolT {
   const char* A; const char* B;
   int acb_all, bcb_all;  // 32-column blocks of the whole operands
   int acb0, bcb0;        // first column block of this workgroup
-  int s0;
-  __device__ __forceinline__ const char* a_tile(int li, int s) const {
+  int s;
+  SlabOut out;
+  __device__ __forceinline__ void advance() { ++s; }
+  __device__ __forceinline__ const char* a_tile(int li) const {
     const int tt = li >> 4, cb = (li >> 1) & 7, p = li & 1;
-    return A + (((long)(2 * (s0 + s) + tt) * acb_all + acb0 + cb) * 2 + p) * gp::TILE_B;
+    return A + (((long)(2 * s + tt) * acb_all + acb0 + cb) * 2 + p) * gp::TILE_B;
   }
-  __device__ __forceinline__ const char* b_tile(int li, int s) const {
+  __device__ __forceinline__ const char* b_tile(int li) const {
     const int tt = li >> 4, cb = (li >> 1) & 7, p = li & 1;
-    return B + (((long)(2 * (s0 + s) + tt) * bcb_all + bcb0 + cb) * 2 + p) * gp::TILE_B;
+    return B + (((long)(2 * s + tt) * bcb_all + bcb0 + cb) * 2 + p) * gp::TILE_B;
   }
+  __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) { out.store(acc); }
 };
 
 template <int DBG, bool TRANS>
@@ -50,27 +74,14 @@ __global__ __launch_bounds__(512) void wgrad_like_kernel(const char* A, const ch
   if (z >= ksplit) return;
   const int chunk = ksteps / ksplit;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
-  f32x4 acc[4][8];
+  const SlabOut out{slabs + (long)z * M * N, N, tm, tn};
   if (TRANS) {
-    PolT pol{A, B, M / 32, N / 32, tm * 8, tn * 8, z * chunk};
-    gp::mainloop<PolT, true, DBG>(pol, chunk, lds, acc);
+    PolT pol{A, B, M / 32, N / 32, tm * 8, tn * 8, z * chunk - 1, out};
+    gp::mainloop<PolT, true, 8, DBG>(pol, chunk, chunk, lds);
   } else {
-    Pol pol{A, B, M / 16, N / 16, tm * 16, tn * 16, z * chunk};
-    gp::mainloop<Pol, false, DBG>(pol, chunk, lds, acc);
+    Pol pol{A, B, M / 16, N / 16, tm * 16, tn * 16, z * chunk - 1, out};
+    gp::mainloop<Pol, false, 8, DBG>(pol, chunk, chunk, lds);
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 15, g = lane >> 4;
-  float* C = slabs + (long)z * M * N;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = tm * 256 + (wm * 4 + mt) * 16 + 4 * g + reg;
-        const int col = tn * 256 + (wn * 8 + nt) * 16 + r;
-        C[(long)row * N + col] = acc[mt][nt][reg];
-      }
 }
 
 __host__ __device__ inline unsigned hash32(unsigned x) {
