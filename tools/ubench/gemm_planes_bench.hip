@@ -64,10 +64,13 @@ struct PolT {
   __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) { out.store(acc); }
 };
 
+__device__ long long g_clk[2];     // shader-clock ticks (s_memtime) and 100 MHz ticks of workgroup 0's main loop
+
 template <int DBG, bool TRANS>
 __global__ __launch_bounds__(512) void wgrad_like_kernel(const char* A, const char* B, float* slabs, int M, int N,
                                                             int ksteps, int ksplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  const long long c0 = clock64(), w0 = wall_clock64();
   const int tiles_m = M / gp::TM, tiles_n = N / gp::TN, per = tiles_m * tiles_n;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int z = (j / per) * 8 + xcd, tile = j % per;
@@ -81,6 +84,10 @@ __global__ __launch_bounds__(512) void wgrad_like_kernel(const char* A, const ch
   } else {
     Pol pol{A, B, M / 16, N / 16, tm * 16, tn * 16, z * chunk - 1, out};
     gp::mainloop<Pol, false, 8, DBG>(pol, chunk, chunk, lds);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk[0] = clock64() - c0;
+    g_clk[1] = wall_clock64() - w0;
   }
 }
 
@@ -192,8 +199,11 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
       const double flop = 2.0 * M * N * 32.0 * big_steps;
-      printf("trans %d dbg %d M %d N %d K %ld ksplit %d: %.3f ms, %.1f TFLOP/s algorithmic, %.1f executed = %.3f of 2500\n", trans, dbg,
-             M, N, 32L * big_steps, ksplit_big, ms, flop / ms * 1e-9, 3 * flop / ms * 1e-9, 3 * flop / ms * 1e-9 / 2500.0);
+      long long hc[2];
+      CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), sizeof(hc)));
+      printf("trans %d dbg %d M %d N %d K %ld ksplit %d: %.3f ms, %.1f TFLOP/s algorithmic, %.1f executed = %.3f of 2500; shader clock %.2f GHz\n",
+             trans, dbg, M, N, 32L * big_steps, ksplit_big, ms, flop / ms * 1e-9, 3 * flop / ms * 1e-9, 3 * flop / ms * 1e-9 / 2500.0,
+             0.1 * (double)hc[0] / (double)hc[1]);
     }
   }
   return 0;

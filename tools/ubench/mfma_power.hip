@@ -13,8 +13,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int SHAPE>   // 0: 16x16x32, 4 x 8 accumulator tiles; 1: 32x32x16, 2 x 4 accumulator tiles (128 registers either way)
-__global__ __launch_bounds__(512) void k(const u32x4* __restrict__ src, float* out, int iters) {
+__global__ __launch_bounds__(512) void k(const u32x4* __restrict__ src, float* out, int iters, long long* clk) {
   const int tid = threadIdx.x;
+  const long long c0 = clock64(), w0 = wall_clock64();
   u32x4 a[4], b[8];
   for (int i = 0; i < 4; ++i) a[i] = src[(i * 512 + tid) & 8191];
   for (int i = 0; i < 8; ++i) b[i] = src[((4 + i) * 512 + tid) & 8191];
@@ -45,11 +46,16 @@ __global__ __launch_bounds__(512) void k(const u32x4* __restrict__ src, float* o
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) r += acc[i][j][0] + acc[i][j][15];
   }
   out[blockIdx.x * 512 + tid] = r;
+  // shader-clock ticks (s_memtime) against the constant 100 MHz counter over the loop: the clock the CU really ran at
+  if (tid == 0 && blockIdx.x == 0) {
+    clk[0] = clock64() - c0;
+    clk[1] = wall_clock64() - w0;
+  }
 }
 
 int main() {
-  u32x4* src; float* out;
-  hipMalloc(&src, 8192 * 16); hipMalloc(&out, 512 * 512 * 4);
+  u32x4* src; float* out; long long* clk;
+  hipMalloc(&src, 8192 * 16); hipMalloc(&out, 512 * 512 * 4); hipMalloc(&clk, 16);
   std::vector<unsigned> h(8192 * 4);
   for (int data = 0; data < 2; ++data) {
     for (auto& v : h) {
@@ -66,15 +72,18 @@ int main() {
         float best = 1e9f;
         for (int rep = 0; rep < 4; ++rep) {
           hipEventRecord(s);
-          if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, src, out, iters);
-          else hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, src, out, iters);
+          if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, src, out, iters, clk);
+          else hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, src, out, iters, clk);
           hipEventRecord(e); hipEventSynchronize(e);
           float ms; hipEventElapsedTime(&ms, s, e);
           if (rep > 0 && ms < best) best = ms;
         }
         const double flops = 256.0 * (threads / 64) * iters * 32.0 * 16384.0;     // 32 MFMAs of 16x16x32 (or 16 of 32x32x16) per iteration
-        printf("%s operands, %s, %d waves/SIMD: %.3f ms  %.0f TFLOP/s\n", data ? "random" : "zero  ",
-               shape ? "32x32x16" : "16x16x32", threads / 256, best, flops / (best * 1e-3) / 1e12);
+        long long hc[2];
+        hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+        printf("%s operands, %s, %d waves/SIMD: %.3f ms  %.0f TFLOP/s   s_memtime ticks / 100 MHz ticks of the last run: %.1f\n",
+               data ? "random" : "zero  ", shape ? "32x32x16" : "16x16x32", threads / 256, best, flops / (best * 1e-3) / 1e12,
+               (double)hc[0] / (double)hc[1]);
       }
   }
   if (hipDeviceSynchronize() != hipSuccess) return 1;
