@@ -573,19 +573,44 @@ def measure_traffic(a):
                 continue
             key = (row["Kernel_Name"], row["Dispatch_Id"])
             per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
-        for (kname, _), v in per.items():
+        for (kname, did), v in sorted(per.items(), key=lambda kv: int(kv[0][1])):     # in dispatch order
             for sub in set(TRAFFIC_KERNELS.values()):
                 if re.search(sub, kname):
                     ent = sums.setdefault(sub, {"FETCH_SIZE": [], "WRITE_SIZE": []})
                     ent[counter].append(v)
     shutil.rmtree(top, ignore_errors=True)
+
+    def entry(fs, ws):
+        f, w = sum(fs) / len(fs), sum(ws) / len(ws)
+        return {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes": int((2 * f + w) * 1024),
+                "launches": len(fs)}
+
     out = {}
     for sub, ent in sums.items():
         if ent["FETCH_SIZE"] and ent["WRITE_SIZE"]:
-            f = sum(ent["FETCH_SIZE"]) / len(ent["FETCH_SIZE"])
-            w = sum(ent["WRITE_SIZE"]) / len(ent["WRITE_SIZE"])
-            out[sub] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
-                        "hbm_bytes": int((2 * f + w) * 1024), "launches": len(ent["FETCH_SIZE"])}
+            out[sub] = entry(ent["FETCH_SIZE"], ent["WRITE_SIZE"])
+    # The input projections and the data gradients are launches of one kernel; the order of its launches inside a
+    # step tells them apart: one projection per layer going up, then one data gradient per layer but the first going down.
+    ent = sums.get("rowgemm_planes_kernel")
+    layers = 1 if a.model == "gaussian" else 3
+    per_step = 2 * layers - 1
+    if ent and len(ent["FETCH_SIZE"]) == len(ent["WRITE_SIZE"]) and len(ent["FETCH_SIZE"]) % per_step == 0:
+        sites = {"inproj_layer0": [0], "inproj_upper_layers": list(range(1, layers)), "dgrad": list(range(layers, per_step))}
+        reads = {"inproj_layer0": 4.0 * a.batch * a.T * ((a.C + 63) // 64 * 64), "inproj_upper_layers": 4.0 * a.batch * a.T * a.H,
+                 "dgrad": 4.0 * a.batch * a.T * 4 * a.H}
+        by_site = {}
+        for site, pos in sites.items():
+            idx = [i for i in range(len(ent["FETCH_SIZE"])) if i % per_step in pos]
+            if idx:
+                e = entry([ent["FETCH_SIZE"][i] for i in idx], [ent["WRITE_SIZE"][i] for i in idx])
+                e["fetched_bytes"] = int(2 * e["FETCH_SIZE_KiB"] * 1024)
+                e["algorithmic_read_bytes"] = int(reads[site])      # the plane operand (the weights stay in the L2)
+                e["fetch_over_algorithmic_reads"] = round(e["fetched_bytes"] / reads[site], 3)
+                by_site[site] = e
+        out["rowgemm_planes_kernel"]["by_call_site"] = by_site
+        out["rowgemm_planes_kernel"]["by_call_site_note"] = (
+            "launch order inside a step: one projection per layer, then one data gradient per layer but the first; "
+            "algorithmic reads = the plane operand once (hi + lo planes = 4 bytes per padded value)")
     return out
 
 
@@ -761,7 +786,8 @@ def main():
         if traffic is not None:
             roofline["traffic_measured"] = traffic
             sub = TRAFFIC_KERNELS.get(dom)
-            if sub in traffic and dom not in ("lstm_inproj_fwd", "lstm_dgrad"):   # those two share one kernel
+            site = {"lstm_inproj_fwd": None, "lstm_dgrad": "dgrad"}.get(dom, "")     # those two share one kernel
+            if sub in traffic and site == "":
                 roofline["traffic"] = traffic[sub]["hbm_bytes"]
                 roofline["traffic_note"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE (KiB), mean "
                                             "over the launches of a 3-step run of this command made by this invocation")
@@ -837,5 +863,15 @@ def main():
         dist.destroy_process_group()
 
 
+def dump_maps():
+    """VTS_BENCH_DUMP_MAPS=<file>: the process's memory map at the end of the run, so that the addresses of a crash
+    report written while the interpreter exits (a profiler's, say) can be matched to the libraries they lie in."""
+    path = os.environ.get("VTS_BENCH_DUMP_MAPS")
+    if path:
+        with open("/proc/self/maps") as src, open(path, "w") as dst:
+            dst.write(src.read())
+
+
 if __name__ == "__main__":
     main()
+    dump_maps()

@@ -46,6 +46,24 @@ def _linear(sd: State, name: str, x: Tensor) -> Tensor:
     return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
 
 
+# Test aid: when a dict, the ReLU sites (the feed-forward blocks "l<i>.ff", decoder.fc1, decoder.fc2) record which
+# units were active.  The reference's gradient jumps wherever a unit changes sides, so a test that compares
+# gradients across implementations first checks that both saw the same pattern.
+RELU_TAPS: Optional[Dict[str, Tensor]] = None
+# ... and, when NEAR_ZERO is a dict, which units' pre-activations lie within NEAR_ZERO_MARGIN of zero: the units whose
+# side a second implementation's rounding could change (a test drops them through the dropout masks it feeds in).
+NEAR_ZERO: Optional[Dict[str, Tensor]] = None
+NEAR_ZERO_MARGIN = 0.0
+
+
+def _relu(name: str, pre: Tensor) -> Tensor:
+    if RELU_TAPS is not None:
+        RELU_TAPS[name] = (pre > 0).detach()
+    if NEAR_ZERO is not None:
+        NEAR_ZERO[name] = (pre.abs() < NEAR_ZERO_MARGIN).detach()
+    return F.relu(pre)
+
+
 def _dropout(x: Tensor, keep: Optional[Tensor]) -> Tensor:
     if keep is None:
         return x
@@ -81,7 +99,7 @@ def encoder_layer(sd: State, i: int, x: Tensor, nhead: int, noise: Dict[str, Ten
     sa = self_attention(sd, p + "self_attn.", x, nhead, noise.get(f"l{i}.attn_keep"))
     x = F.layer_norm(x + _dropout(sa, noise.get(f"l{i}.drop1_keep")), (d,), sd[p + "norm1.weight"],
                      sd[p + "norm1.bias"], LN_EPS)
-    ff = _dropout(F.relu(_linear(sd, p + "linear1", x)), noise.get(f"l{i}.ff_keep"))
+    ff = _dropout(_relu(f"l{i}.ff", _linear(sd, p + "linear1", x)), noise.get(f"l{i}.ff_keep"))
     ff = _linear(sd, p + "linear2", ff)
     return F.layer_norm(x + _dropout(ff, noise.get(f"l{i}.drop2_keep")), (d,), sd[p + "norm2.weight"],
                         sd[p + "norm2.bias"], LN_EPS)
@@ -111,8 +129,8 @@ def sample(mean, logvar, scale, shape, pi_params, noise) -> Tensor:
 
 def decode(sd: State, z: Tensor, dec_keep: Optional[Tensor]) -> Tensor:
     """mixture-vae-transformer.py:67-72 (dense1 is registered but unused)."""
-    z = F.relu(_linear(sd, "decoder.fc1", z))
-    z = _dropout(F.relu(_linear(sd, "decoder.fc2", z)), dec_keep)
+    z = _relu("decoder.fc1", _linear(sd, "decoder.fc1", z))
+    z = _dropout(_relu("decoder.fc2", _linear(sd, "decoder.fc2", z)), dec_keep)
     return _linear(sd, "decoder.final_fcn", _linear(sd, "decoder.out", z))
 
 

@@ -175,6 +175,42 @@ def adam_trajectory(root, kind, lr, steps=5, seed=7, tweak=None, tag=None):
     print(f"{name}: losses={losses}")
 
 
+def adam_trajectory_real_data(root, steps=8, seed=41):
+    """The reference's first configuration on its own data: the Gaussian model's train loop
+    (gaussian-lstm-DE.py:100-156: the five tensors of the data split, DataLoader(batch_size=16, shuffle=True),
+    Adam(lr=5e-3)) for the first `steps` batches of an epoch.  The script reads "data_split.pt" from its working
+    directory; the committed file is datasets/deep-extrema-data-split.pt.  The loader's shuffle is seeded here, and
+    the batches it produced are stored (windows of the data set: data, 16 x 16 x 1 floats each)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    ns = load_reference(root, "gaussian", 95.0)
+    split = torch.load(os.path.join(root, "datasets", "deep-extrema-data-split.pt"), map_location="cpu", weights_only=True)
+    X_train, y_train = split[0].float(), split[1].float()
+    B, T, C, H, L = 16, X_train.shape[1], X_train.shape[2], 64, 32        # gaussian-lstm-DE.py:108-114
+    torch.manual_seed(seed)
+    model = ns["VAE"](input_dim=C, lstm_output_dim=H, latent_dim=L, future_steps=1)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    loader = DataLoader(TensorDataset(X_train, y_train), batch_size=B, shuffle=True,
+                        generator=torch.Generator().manual_seed(seed + 1))
+    blob = {"meta/dims": np.array([B, T, C, H, L, 1], dtype=np.int64), "meta/threshold": np.float64(95.0),
+            "meta/beta": np.float64(model.beta), "meta/lr": np.float64(5e-3), "meta/steps": np.int64(steps),
+            "meta/train_rows": np.int64(X_train.shape[0])}
+    blob.update(pack("sd0", model.state_dict()))
+    losses = []
+    for s, (x, y) in enumerate(loader):
+        if s == steps:
+            break
+        opt.zero_grad()
+        loss, _, noise = run_once(ns, "gaussian", model, x, y, True)
+        opt.step()
+        losses.append(float(loss))
+        blob[f"step{s}/x"], blob[f"step{s}/y"] = x.numpy().copy(), y.numpy().copy()
+        blob.update(pack(f"step{s}/noise", noise))
+    blob["losses"] = np.array(losses, dtype=np.float32)
+    blob.update(pack("sdK", model.state_dict()))
+    np.savez(os.path.join(HERE, "adam_gaussian_real_data.npz"), **blob)
+    print(f"adam_gaussian_real_data: X_train {tuple(X_train.shape)}, losses={losses}")
+
+
 def main():
     if len(sys.argv) < 2 or not os.path.isdir(sys.argv[1]):
         print("reference tree not given / not present: nothing to do")
@@ -187,6 +223,9 @@ def main():
                 model.encoder.shape_layer_extreme.weight.mul_(0.25)
                 model.encoder.shape_layer_extreme.bias.fill_(0.5)
         adam_trajectory(root, "gpd", 1e-3, tweak=well_conditioned, tag="adam_gpd_native_wellcond")
+        return
+    if len(sys.argv) > 2 and sys.argv[2] == "--only-real-data-trajectory":  # adds that one fixture, leaves the rest
+        adam_trajectory_real_data(root)
         return
     for kind in SCRIPTS:
         for si, shape_name in enumerate(SHAPES):
@@ -222,6 +261,7 @@ def main():
     # the GPD train loop (gpd-lstm-DE.py:99-105) from a state whose sampler is well conditioned: a trajectory
     # that can be held to the same bounds as the other two models
     adam_trajectory(root, "gpd", 1e-3, tweak=well_conditioned, tag="adam_gpd_native_wellcond")
+    adam_trajectory_real_data(root)
 
 
 if __name__ == "__main__":

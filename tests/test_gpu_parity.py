@@ -426,14 +426,16 @@ def test_gpd_sampler_is_bit_exact_at_the_clamp():
 
 
 # --------------------------------------------------------------------------- Adam, a10
-@pytest.mark.parametrize("kind", ["gaussian", "mixture", "gpd", "gpd_wellcond"])
+@pytest.mark.parametrize("kind", ["gaussian", "mixture", "gpd", "gpd_wellcond", "gaussian_real"])
 def test_adam_trajectory(golden, kind):
     """Five steps of the reference's train loop (gaussian-lstm-DE.py:149-156, gpd-lstm-DE.py:99-105,
     mixture-vae-DE.py:158-164) replayed with its recorded inputs and draws.  gpd_wellcond: the GPD loop from a state
-    whose sampler is well conditioned (shape head biased to 0.5), held to the bounds of the other two models."""
+    whose sampler is well conditioned (shape head biased to 0.5), held to the bounds of the other two models.
+    gaussian_real: the reference's first configuration on its own data - eight shuffled 16-window batches of
+    datasets/deep-extrema-data-split.pt through the Gaussian model's loop (gaussian-lstm-DE.py:100-156, lr 5e-3)."""
     import vts
     dev = _dev()
-    g = golden(f"adam_{kind}_native" if kind != "gpd_wellcond" else "adam_gpd_native_wellcond")
+    g = golden({"gpd_wellcond": "adam_gpd_native_wellcond", "gaussian_real": "adam_gaussian_real_data"}.get(kind, f"adam_{kind}_native"))
     dims = [int(v) for v in g["meta"]["dims"]]
     m = make_model(kind.split("_")[0], dims, g["sd0"], g["meta"]["threshold"], g["meta"]["beta"], dev)
     m.train()

@@ -99,9 +99,11 @@ def test_clamped_shape_gets_no_gradient(golden):
     assert torch.all(grads["encoder.shape_layer_extreme.weight"] == 0)
 
 
-@pytest.mark.parametrize("kind", ["gaussian", "gpd", "mixture", "gpd_wellcond"])
+@pytest.mark.parametrize("kind", ["gaussian", "gpd", "mixture", "gpd_wellcond", "gaussian_real"])
 def test_adam_trajectory(golden, kind):
-    g = golden(f"adam_{kind}_native" if kind != "gpd_wellcond" else "adam_gpd_native_wellcond")
+    """gaussian_real: the reference's first configuration on its own data - eight shuffled 16-window batches of
+    datasets/deep-extrema-data-split.pt through the Gaussian model's loop (gaussian-lstm-DE.py:100-156, lr 5e-3)."""
+    g = golden({"gpd_wellcond": "adam_gpd_native_wellcond", "gaussian_real": "adam_gaussian_real_data"}.get(kind, f"adam_{kind}_native"))
     if kind == "gpd_wellcond":   # GPD shapes well above the clamp: held to the bounds of the other models
         kind = "gpd_tight"
     sd = {k: v.clone() for k, v in g["sd0"].items()}

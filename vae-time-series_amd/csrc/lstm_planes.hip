@@ -96,22 +96,25 @@ __global__ void zero_slot0_kernel(SeqPlanes p, long nbt) {   // the zero "step b
 }
 
 // ---- rows x weights: input projection and data gradient ------------------------------------------------------
-// out[tile16 of [tokens, N]] = A[tokens, K] . Wt[N, K]^T (+ bias0 + bias1).  A workgroup owns a run of output
-// tiles (256 tokens x 256 columns, the column tiles of a token block one after the other, so the block's A tiles
-// are re-read from the L2) and streams their k-steps as one sequence through the ring: the loads of the next
-// tile's first k-steps are in flight while a tile's accumulators are written out.
+// out[tile16 of [tokens, N]] = A[tokens, K] . Wt[N, K]^T (+ bias0 + bias1).  A workgroup owns a sequence of output
+// tiles (256 tokens x 256 columns; tile ids start, start + step, ...: id = token block * ntn + column tile) and
+// streams their k-steps as one sequence through the ring: the loads of the next tile's first k-steps are in flight
+// while a tile's accumulators are written out.  Two ways to hand out the tiles (rowgemm_planes_kernel): a run of
+// consecutive ids (a token block's column tiles one after the other in one workgroup), or - several column tiles -
+// the column tiles of a token block side by side on ntn workgroups of one XCD, which walk the same token blocks in
+// step so that a block's A tiles come from HBM once and from that XCD's L2 the other ntn - 1 times.
 struct RowPol {
   SeqPlanes A;
   const char* W; int w_ncb;
   int T, nk, ntn, N;
   float* out; const float* bias0; const float* bias1;
   int wave, lane;
-  int is_tile, is_ks, fl_tile;
+  int is_tile, is_ks, fl_tile, step;
   const char *a0, *a1, *b0, *b1;
   __device__ __forceinline__ void advance() {
     if (++is_ks == nk) {
       is_ks = 0;
-      ++is_tile;
+      is_tile += step;
       const int tb = is_tile / ntn, tn = is_tile - tb * ntn;
       const int idx = tb * 16 + 2 * wave;             // first of this wave's two token tiles (T is even: same window tile)
       const int bt = idx / T, t = idx - bt * T;
@@ -125,7 +128,8 @@ struct RowPol {
   __device__ __forceinline__ const char* a_tile(int li) const { return ((li & 2) ? a1 : a0) + (is_ks * 2 + (li & 1)) * TILE_B; }
   __device__ __forceinline__ const char* b_tile(int li) const { return ((li & 2) ? b1 : b0) + (is_ks * 2 + (li & 1)) * TILE_B; }
   __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) {
-    const int tile = fl_tile++;
+    const int tile = fl_tile;
+    fl_tile += step;
     const int tb = tile / ntn, tn = tile - tb * ntn;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 15;
 #pragma unroll
@@ -152,18 +156,29 @@ struct RowPol {
 
 __global__ __launch_bounds__(512) void rowgemm_planes_kernel(SeqPlanes A, const char* W, int w_ncb, int T, int nk,
                                                              int ntn, int N, float* out, const float* bias0,
-                                                             const float* bias1, int ntiles_all) {
+                                                             const float* bias1, int ntiles_all, int colsplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  // contiguous runs of tiles per workgroup, token-block aligned where possible
-  const long lo = (long)blockIdx.x * ntiles_all / gridDim.x, hi = (long)(blockIdx.x + 1) * ntiles_all / gridDim.x;
-  const int n = (int)(hi - lo);
+  int start, step, n;
+  if (colsplit) {
+    // workgroup b runs on XCD b % 8: the ntn workgroups j = ntn * g' + tn of an XCD form a group that shares its
+    // token blocks, one column tile each
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, gpx = (int)(gridDim.x >> 3) / ntn;
+    if (j >= gpx * ntn) return;
+    const int g = xcd * gpx + j / ntn, ng = 8 * gpx, ntb = ntiles_all / ntn;
+    const long lo = (long)g * ntb / ng, hi = (long)(g + 1) * ntb / ng;
+    start = (int)lo * ntn + j % ntn; step = ntn; n = (int)(hi - lo);
+  } else {
+    // a run of consecutive tiles per workgroup
+    const long lo = (long)blockIdx.x * ntiles_all / gridDim.x, hi = (long)(blockIdx.x + 1) * ntiles_all / gridDim.x;
+    start = (int)lo; step = 1; n = (int)(hi - lo);
+  }
   if (n <= 0) return;
   RowPol pol;
   pol.A = A; pol.W = W; pol.w_ncb = w_ncb; pol.T = T; pol.nk = nk; pol.ntn = ntn; pol.N = N;
   pol.out = out; pol.bias0 = bias0; pol.bias1 = bias1;
   pol.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   pol.lane = threadIdx.x & 63;
-  pol.is_tile = (int)lo - 1; pol.is_ks = nk - 1; pol.fl_tile = (int)lo;
+  pol.step = step; pol.is_tile = start - step; pol.is_ks = nk - 1; pol.fl_tile = start;
   gp::mainloop<RowPol, false>(pol, n * nk, nk, lds);
 }
 
@@ -351,8 +366,11 @@ int vts_planes_inproj(const void* s_planes, int a_zero_slot, const float* w_ih, 
   SeqPlanes A = seq_planes(const_cast<void*>(s_planes), T, Cin, a_zero_slot);
   const int ntb = (int)(B / 16 * T / 16), ntn = N / 256;
   const int grid = min(grid_cus(), ntb);
+  // column tiles side by side when every XCD gets whole groups with at least one token block each
+  static const int want_split = getenv("VTS_ROW_COLSPLIT") ? atoi(getenv("VTS_ROW_COLSPLIT")) : 1;
+  const int colsplit = want_split && grid % (8 * ntn) == 0 && ntb >= grid / ntn;
   hipLaunchKernelGGL(rowgemm_planes_kernel, dim3(grid), dim3(512), gp::LDS_B, st, A, reinterpret_cast<const char*>(wplanes),
-                     ncb, (int)T, ncb, ntn, N, gates, b_ih, b_hh, ntb * ntn);
+                     ncb, (int)T, ncb, ntn, N, gates, b_ih, b_hh, ntb * ntn, colsplit);
   VTS_CHECK_LAUNCH("rowgemm_planes(inproj)");
   return VTS_OK;
 }
@@ -369,7 +387,7 @@ int vts_planes_dgrad(const void* dg_planes, const float* w_ih, float* dx_t16, vo
   const int ntb = (int)(B / 16 * T / 16), ntn = (int)(Cin / 256);
   const int grid = min(grid_cus(), ntb);
   hipLaunchKernelGGL(rowgemm_planes_kernel, dim3(grid), dim3(512), gp::LDS_B, st, A, reinterpret_cast<const char*>(wplanes),
-                     ncb, (int)T, ncb, ntn, (int)Cin, dx_t16, nullptr, nullptr, ntb * ntn);
+                     ncb, (int)T, ncb, ntn, (int)Cin, dx_t16, nullptr, nullptr, ntb * ntn, 0);
   VTS_CHECK_LAUNCH("rowgemm_planes(dgrad)");
   return VTS_OK;
 }

@@ -697,10 +697,13 @@ extern "C" void vts_debug_set_cluster_fault(int member) { g_fault_member.store(m
 size_t vts_lstm_rec3c_xchg_bytes(int B) { return (size_t)(B / CROWS) * X_CLUSTER; }
 size_t vts_lstm_rec3c_flag_bytes(int B) { return ((size_t)(B / CROWS) * NC + 1) * FLAG_STRIDE * sizeof(unsigned); }
 
-// Returns VTS_OK, an error, or VTS_ERR_UNSUPPORTED with nothing launched when the runtime will not guarantee that
-// the whole grid is resident at once (another tenant on the device, a CU mask, too few CUs): the caller then takes
-// the one-workgroup kernel.  The launch is a cooperative one for exactly that guarantee: the members of a cluster
-// wait for each other, so a grid that is only partly resident would spin until the polls time out.
+// Returns VTS_OK, an error, or VTS_ERR_UNSUPPORTED when the runtime will not guarantee that the whole grid is
+// resident at once (another tenant on the device, a CU mask, too few CUs) or the stream is recording a graph: the
+// caller then takes the one-workgroup kernel.  The occupancy and capture tests refuse before anything is enqueued;
+// a refusal by the cooperative launch itself comes after the packing kernel is in the queue, which has then
+// overwritten Wp, the flags and the status word - harmless, because the fall-back kernel packs Wp again and the
+// caller clears the status word.  The launch is a cooperative one for exactly that guarantee: the members of a
+// cluster wait for each other, so a grid that is only partly resident would spin until the polls time out.
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
                        void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream) {
   const int nclusters = B / CROWS;
@@ -715,6 +718,10 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
   static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return !(e && e[0] == '0'); }();
   const unsigned grid = 64 * vts_cdiv(nclusters, 8);
   if (coop) {
+    if (vts_stream_is_capturing(stream)) {
+      vts_set_error("lstm_rec3c_fwd: cooperative launches cannot be recorded into a graph");
+      return VTS_ERR_UNSUPPORTED;
+    }
     // what the runtime would refuse at launch, asked beforehand so that nothing has been enqueued on a refusal
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -762,7 +769,7 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
 
 size_t vts_lstm_rec3c_bwd_flag_bytes(int B) { return (size_t)(B / CROWS) * 4 * NC * FLAG_STRIDE * sizeof(unsigned); }
 
-// Backward counterpart: same contract as vts_lstm_rec3c_fwd (VTS_ERR_UNSUPPORTED with nothing launched when the
+// Backward counterpart: same contract as vts_lstm_rec3c_fwd (VTS_ERR_UNSUPPORTED - see there for what may have been enqueued - when the
 // grid cannot be guaranteed resident).  dhlast / dclast are tile16 [B, 256] blocks or null; dg_planes is the
 // gate-gradient plane buffer (T step slots per window tile, 32 column blocks); fws holds the flag words.
 int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
@@ -773,6 +780,10 @@ int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, co
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_bwd_kernel), CB_LDS, &lds_done, "lstm_rec3c_bwd"))
     return rc;
   const unsigned grid = 64 * vts_cdiv(nclusters, 8);
+  if (vts_stream_is_capturing(stream)) {
+    vts_set_error("lstm_rec3c_bwd: cooperative launches cannot be recorded into a graph");
+    return VTS_ERR_UNSUPPORTED;
+  }
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||

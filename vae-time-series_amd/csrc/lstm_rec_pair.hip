@@ -56,6 +56,10 @@ constexpr int XW = NI * 1024;                 // bytes one wave publishes per st
 constexpr int XSLOTS = 3;
 constexpr int X_SLOTS_B = XSLOTS * 2 * 4 * XW;   // [slot][destination member][wave] = 96 KiB per pair
 constexpr int X_PAIR = X_SLOTS_B + 256;       // ... and, behind them, one word per member: where it runs (below)
+// "nothing here yet".  As a float this is a NaN with an all-ones payload, which no arithmetic instruction of this
+// GPU produces (they return the canonical quiet NaN 0x7fc00000 or pass an operand's NaN on): a partial sum can only
+// carry it if the caller's own tensors held that exact bit pattern, and the launch then ends as a missed hand-off
+// does - NaN gradients and bit 1 of the status word - after the bounded reads have run out.
 constexpr unsigned EMPTY = 0xffffffffu;
 constexpr int SC1 = 16;                       // cache-policy operand of the buffer builtins: agent scope
 typedef unsigned pvec4 __attribute__((vector_size(16)));
@@ -566,8 +570,12 @@ bool vts_lstm_rec3p_usable(int B, int T, int H) {
   return 16 * vts_cdiv(B / PROWS, 8) <= cus;
 }
 
-// Same contract as vts_lstm_rec3c_bwd: VTS_OK, an error, or VTS_ERR_UNSUPPORTED with nothing launched when the
-// runtime will not guarantee that the whole grid is resident at once.  xws: vts_lstm_rec3p_xchg_bytes(B) bytes.
+// Same contract as vts_lstm_rec3c_bwd: VTS_OK, an error, or VTS_ERR_UNSUPPORTED when the runtime will not guarantee
+// that the whole grid is resident at once.  The occupancy test refuses before anything is enqueued; a refusal by the
+// cooperative launch itself comes after the packing kernel is in the queue, which has then overwritten Wp, the
+// exchange buffer and the status word - harmless, because the caller's fall-back kernel packs Wp again and clears
+// the status word itself.  Under stream capture a cooperative launch cannot be recorded: that, too, is reported as
+// VTS_ERR_UNSUPPORTED before anything is enqueued.  xws: vts_lstm_rec3p_xchg_bytes(B) bytes.
 int vts_lstm_rec3p_bwd(const float* G, const float* cseq, const float* dhseq, const float* dhlast, const float* dclast,
                        float* dbpart, const float* W_hh, float* Wp, void* dg_planes, void* xws, unsigned* err, int B, int T,
                        hipStream_t stream) {
@@ -584,6 +592,10 @@ int vts_lstm_rec3p_bwd(const float* G, const float* cseq, const float* dhseq, co
       (long)per_cu * cus < (long)grid) {
     (void)hipGetLastError();
     vts_set_error("lstm_rec3p_bwd: %u workgroups cannot be resident at once (%d per CU x %d CUs)", grid, per_cu, cus);
+    return VTS_ERR_UNSUPPORTED;
+  }
+  if (vts_stream_is_capturing(stream)) {
+    vts_set_error("lstm_rec3p_bwd: cooperative launches cannot be recorded into a graph");
     return VTS_ERR_UNSUPPORTED;
   }
   u32x4* img = reinterpret_cast<u32x4*>(Wp);

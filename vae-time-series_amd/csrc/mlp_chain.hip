@@ -467,7 +467,11 @@ int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
                            float* const* db, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (int rc = chain_check(d, B)) return rc;
   VTS_REQUIRE(workspace != nullptr && workspace_bytes >= vts_mlp_chain_bwd_workspace_bytes_impl(d, B), "mlp chain: workspace too small");
-  VTS_REQUIRE(x != nullptr && dw != nullptr && d_head != nullptr, "mlp chain: missing argument");
+  VTS_REQUIRE(x != nullptr && w != nullptr && dw != nullptr && d_head != nullptr && head_out != nullptr &&
+                  (d->n_trunk == 0 || trunk_out != nullptr),
+              "mlp chain: missing argument");
+  VTS_REQUIRE(vts_aligned16(x) && ldx % 4 == 0 && ldx >= d->in_dim, "mlp chain: input must be 16-byte aligned with a row stride that is a multiple of 4");
+  VTS_REQUIRE(dx == nullptr || lddx >= d->in_dim, "mlp chain: dx row stride shorter than the input width");
   Chain D;
   chain_fill(D, d);
   ChainBwd R{};
@@ -475,7 +479,7 @@ int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
   float* ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
   int tiles = 0;
   for (int i = 0; i < nm; ++i) {
-    VTS_REQUIRE(w[i] != nullptr && dw[i] != nullptr, "mlp chain: weight or weight gradient %d missing", i);
+    VTS_REQUIRE(w[i] != nullptr && vts_aligned16(w[i]) && dw[i] != nullptr, "mlp chain: weight %d missing or not 16-byte aligned, or its gradient missing", i);
     D.w[i] = w[i];
     R.dw[i] = dw[i];
     R.db[i] = db != nullptr ? db[i] : nullptr;
@@ -486,6 +490,7 @@ int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
   }
   R.tile0[nm] = tiles;
   for (int i = 0; i < d->n_trunk; ++i) {
+    VTS_REQUIRE(trunk_out[i] != nullptr, "mlp chain: trunk output %d missing", i);
     D.tout[i] = trunk_out[i];
     D.keep[i] = (keep != nullptr && d->trunk_act[i] == 4) ? keep[i] : nullptr;
     R.dpre_t[i] = ws;
@@ -493,10 +498,11 @@ int vts_mlp_chain_bwd_impl(const vts_mlp_chain_desc* d, const float* x, long ldx
   }
   R.dpre_h = ws;
   for (int i = 0; i < d->n_heads; ++i) {
+    VTS_REQUIRE(head_out[i] != nullptr, "mlp chain: head output %d missing", i);
     D.hout[i] = head_out[i];
     D.haux[i] = head_aux != nullptr ? head_aux[i] : nullptr;
     VTS_REQUIRE(d->head_act[i] != 3 || D.haux[i] != nullptr, "mlp chain: head %d clamps and needs its aux buffer", i);
-    R.dhead[i] = d_head[i];
+    R.dhead[i] = d_head[i];              // (a head without an upstream gradient passes NULL)
   }
   R.dx = dx;
   R.lddx = lddx;

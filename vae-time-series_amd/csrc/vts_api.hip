@@ -207,9 +207,10 @@ static size_t rec_ws_seed_bytes(int64_t B, int64_t H) { return round256((size_t)
 // ... [status word of the launch, 256 B][hand-off flags of the backward cluster kernel: four 128-byte lines per 16 windows]
 static size_t rec_ws_bflag_bytes(int64_t B) { return round256((size_t)(pad16(B) / 16) * 512); }
 // ... [exchange buffer of the backward pair kernel: hidden 256 and whole pairs of window tiles, up to the largest
-// batch whose grid can be resident at once on any device this library runs on]
+// batch whose grid (one workgroup per 16 windows) is resident at once on the 256 CUs of the one device this library
+// is built for; larger batches never take the pair kernel (vts_lstm_rec3p_usable) and carry no such region]
 static size_t rec_ws_pair_bytes(int64_t B, int64_t H) {
-  return (H == 256 && B % 32 == 0 && B <= 16384) ? round256(vts_lstm_rec3p_xchg_bytes((int)B)) : 0;
+  return (H == 256 && B % 32 == 0 && B <= 4096) ? round256(vts_lstm_rec3p_xchg_bytes((int)B)) : 0;
 }
 size_t vts_lstm_recurrent_workspace_bytes(int64_t B, int64_t T, int64_t H) {
   (void)T;
@@ -290,7 +291,7 @@ static int recurrent_fwd_impl(float* gates, float* cells, float* hseq, float* h_
     char* xws = fws + rec_ws_dbpart_bytes(B, H);
     const int rc = vts_lstm_rec3c_fwd(gates, cells, hseq, h_last, c_last, w_hh, reinterpret_cast<float*>(workspace), xws, fws,
                                       status, (int)B, (int)T, h_planes, reinterpret_cast<hipStream_t>(stream));
-    // the runtime would not guarantee a resident grid: nothing was launched, take the one-workgroup kernel
+    // the runtime would not guarantee a resident grid (at most the packing kernel ran): take the one-workgroup kernel
     if (rc != VTS_ERR_UNSUPPORTED) return rc;
   }
   if (hipMemsetAsync(status, 0, sizeof(unsigned), reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
@@ -356,6 +357,10 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
   float* wpack = reinterpret_cast<float*>(workspace);
   float* dbpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + rec_ws_pack_bytes(H));
   const int nbt = (int)(pad16(B) / 16);
+  // status word of this launch (vts_lstm_recurrent_bwd_status): the pair kernel's packing launch and the cluster
+  // branch clear it themselves; for every other kernel - none of which can set it - it is cleared below, so that
+  // the query never returns what an earlier launch or the allocator left in the workspace
+  bool status_cleared = false;
   if (dtype_mode == 1 && vts_lstm_rec3_supported((int)H)) {
     // the bf16x3 kernel takes the gradients w.r.t. h_T / c_T as tile16 blocks (one coalesced load
     // per accumulator tile instead of per-lane row gathers inside a register-bound kernel)
@@ -365,7 +370,7 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
     if (seed_h) VTS_RC(vts_ew_tile16_convert(dh_last, seed_h, (int)B, 1, (int)H, 0, st));
     if (seed_c) VTS_RC(vts_ew_tile16_convert(dc_last, seed_c, (int)B, 1, (int)H, 0, st));
     // plane output at bench size: W_hh stationary in clusters of eight workgroups, as the forward pass; when the
-    // runtime will not guarantee a resident grid nothing was launched and the one-workgroup kernel takes over
+    // runtime will not guarantee a resident grid (at most a packing kernel ran) the one-workgroup kernel takes over
     // (Off unless asked for - VTS_LSTM_CLUSTER_BWD=1 at start-up or vts_debug_set_cluster_bwd(1): measured at
     // 4096 x 96, hidden 256, it is 3 % slower than the one-workgroup kernel.  Its members exchange dA, four
     // times the forward kernel's h, and a CU's vector memory pipe moves the 610 KiB a step then needs no faster
@@ -379,6 +384,7 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
       rc = vts_lstm_rec3p_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, dg_planes,
                               reinterpret_cast<char*>(status) + 256 + rec_ws_bflag_bytes(B), status, (int)B, (int)T, st);
       if (rc != VTS_OK && rc != VTS_ERR_UNSUPPORTED) return rc;
+      status_cleared = rc == VTS_OK;
     }
     if (rc == VTS_ERR_UNSUPPORTED && dg_planes && g_cluster_bwd.load() > 0 && vts_lstm_rec3c_usable((int)B, (int)T, (int)H)) {
       unsigned* status = rec_ws_status(workspace, B, H);
@@ -389,6 +395,7 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
       rc = vts_lstm_rec3c_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, dg_planes,
                               reinterpret_cast<char*>(status) + 256, status, (int)B, (int)T, st);
       if (rc != VTS_OK && rc != VTS_ERR_UNSUPPORTED) return rc;
+      status_cleared = true;
     }
     if (rc == VTS_ERR_UNSUPPORTED)
     VTS_RC(vts_lstm_rec3_bwd(gates, cells, dh_seq_t16, seed_h, seed_c, dbpart, w_hh, wpack, (int)B, (int)T, (int)H,
@@ -396,6 +403,10 @@ static int recurrent_bwd_impl(float* gates, const float* cells, const float* dh_
   } else {
     VTS_REQUIRE(!dg_planes, "lstm_recurrent_bwd: plane output needs dtype_mode 1 and a hidden size of 256");
     VTS_RC(vts_lstm_rec_bwd(gates, cells, dh_seq_t16, dh_last, dc_last, dbpart, w_hh, wpack, (int)B, (int)T, (int)H, st));
+  }
+  if (!status_cleared && hipMemsetAsync(rec_ws_status(workspace, B, H), 0, sizeof(unsigned), st) != hipSuccess) {
+    vts_set_error("lstm_recurrent_bwd: clearing the status word failed");
+    return VTS_ERR_HIP;
   }
   if (db_ih && db_hh && db_ih != db_hh) VTS_RC(vts_colsum_partials2(dbpart, db_ih, db_hh, nbt, (int)(4 * H), 4 * H, accumulate, st));
   else if (db_ih) VTS_RC(vts_colsum_partials(dbpart, db_ih, nbt, (int)(4 * H), 4 * H, accumulate, st));

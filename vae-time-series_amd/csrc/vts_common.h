@@ -53,6 +53,17 @@ static inline int vts_reserve_lds(const void* kernel, size_t bytes, vts_lds_mask
   return VTS_OK;
 }
 
+// A stream that is recording a graph takes no cooperative launch; the launchers of the cooperative kernels ask
+// first and report VTS_ERR_UNSUPPORTED with nothing enqueued, so that their callers take the plain kernels.
+static inline bool vts_stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return cs != hipStreamCaptureStatusNone;
+}
+
 static inline bool vts_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int vts_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

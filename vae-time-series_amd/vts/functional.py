@@ -29,6 +29,8 @@ _FUSED_CHAINS = os.environ.get("VTS_FUSED_CHAINS", "1")[:1] != "0"
 CHAIN_MAX_ROWS = 16384
 # test aid: when a dict, mlp_chain stores the trunk outputs of every chain it runs under the names it was given
 CHAIN_TAPS = None
+# test aid: when a list, feed_forward appends the hidden activations dropout(relu(linear1(x))) of every block it runs
+FFN_TAPS = None
 
 
 def set_fused_chains(on: bool) -> None:
@@ -65,6 +67,77 @@ def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------- LSTM
+class RecurrenceTimeout(RuntimeError):
+    """A cooperative recurrent kernel gave up waiting for a peer workgroup; its outputs are NaN."""
+
+
+class _RecurrenceStatus:
+    """Status words of the recurrent launches of the current step.
+
+    The cluster forward kernel and the pair backward kernel (bf16x3, hidden 256) are grids of workgroups that wait
+    for each other with bounded polls.  A workgroup that never hears from its peer writes NaN and sets its launch's
+    status word (vts_lstm_recurrent_{fwd,bwd}_status).  torch's own LSTM would raise on the host; here every launch
+    that can time out copies its word into a small device array (stream-ordered, four bytes), and
+    ``raise_on_timeout`` - called by train_step and DataParallelTrainer before the optimizer update - reads the
+    array back and raises RecurrenceTimeout naming the kernel, so that NaN gradients never reach the parameters.
+    Reading back is one host synchronisation per step, made only in steps that ran such a kernel."""
+
+    SLOTS = 64
+
+    def __init__(self):
+        self.enabled = True
+        self.words = {}     # device index -> int32[SLOTS]
+        self.names = {}     # device index -> names of the launches noted since the last read
+
+    def note(self, name: str, query, ws, ws_bytes: int, B: int, T: int, H: int) -> None:
+        if not self.enabled or H != 256 or _MODE != 1 or torch.cuda.is_current_stream_capturing():
+            return          # (other shapes and modes run one-workgroup kernels, which cannot time out)
+        dev = ws.device.index
+        words = self.words.get(dev)
+        if words is None:
+            words = self.words[dev] = torch.zeros(self.SLOTS, dtype=torch.int32, device=ws.device)
+        names = self.names.setdefault(dev, [])
+        if len(names) >= self.SLOTS:        # nobody has read for a long while: keep the oldest, drop the rest
+            return
+        slot = words[len(names):len(names) + 1]
+        L.check(query(L.wptr(ws), ws_bytes, B, T, H, C.c_void_p(slot.data_ptr()), L.stream()), "vts_lstm_recurrent_status")
+        names.append(name)
+
+    def begin_step(self) -> None:
+        """Forget launches that nobody asked about (a step that ended in an exception, forward-only calls)."""
+        for dev in self.names:
+            self.names[dev] = []
+
+    def read(self, device=None):
+        """[(launch name, status word)] of the launches noted since the last read (synchronises with the device)."""
+        out = []
+        for dev, names in self.names.items():
+            if names and (device is None or torch.device(device).index in (None, dev)):
+                vals = self.words[dev][:len(names)].cpu().tolist()
+                out += list(zip(names, vals))
+                self.names[dev] = []
+        return out
+
+    def raise_on_timeout(self) -> None:
+        if not self.enabled or not any(self.names.values()) or torch.cuda.is_current_stream_capturing():
+            return
+        bad = [(n, v) for n, v in self.read() if v != 0]
+        if bad:
+            raise RecurrenceTimeout(
+                "a workgroup of " + ", ".join(f"{n} (status {v:#x})" for n, v in bad) + " gave up waiting for its peer "
+                "(another kernel held compute units for longer than the poll bound, about a second): the launch's "
+                "outputs are NaN and no optimizer update was made.  VTS_LSTM_CLUSTER=0 / VTS_LSTM_PAIR_BWD=0 select "
+                "the one-workgroup kernels, which wait for nobody.")
+
+
+recurrence_status = _RecurrenceStatus()
+
+
+def set_status_checks(on: bool) -> None:
+    """Turn the per-step read-back of the cooperative recurrences' status words on (default) or off."""
+    recurrence_status.enabled = bool(on)
+
+
 class _LayerCfg:
     """Static facts of one layer of a stack, shared by its forward and backward."""
 
@@ -120,6 +193,8 @@ class _LSTMLayer(torch.autograd.Function):
             L.check(L.timer.call("lstm_recurrent_fwd", lib.vts_lstm_recurrent_fwd_planes, L.wptr(gates), L.wptr(cells),
                                  L.ptr(hseq), L.wptr(hp), L.ptr(h_last), L.ptr(c_last), L.ptr(w_hh), L.wptr(ws), ws_bytes,
                                  B, T, H, mode, st), "vts_lstm_recurrent_fwd_planes")
+            recurrence_status.note("the forward recurrence (lstm_rec3c_fwd_kernel)", lib.vts_lstm_recurrent_fwd_status, ws,
+                                   ws_bytes, B, T, H)
             ctx.save_for_backward(xp, gates, cells, hp, w_ih, w_hh)
         else:
             x_rows = inp if cfg.first else inp   # rows either way; only the first B windows of a padded tensor are read
@@ -128,6 +203,8 @@ class _LSTMLayer(torch.autograd.Function):
             L.check(L.timer.call("lstm_recurrent_fwd", lib.vts_lstm_recurrent_fwd, L.wptr(gates), L.wptr(cells),
                                  L.ptr(hseq), L.ptr(h_last), L.ptr(c_last), L.ptr(w_hh), L.wptr(ws), ws_bytes,
                                  B, T, H, mode, st), "vts_lstm_recurrent_fwd")
+            recurrence_status.note("the forward recurrence (lstm_rec3c_fwd_kernel)", lib.vts_lstm_recurrent_fwd_status, ws,
+                                   ws_bytes, B, T, H)
             hp = None
             ctx.save_for_backward(x_rows, gates, cells, hseq, w_ih, w_hh)
         ctx.cfg = cfg
@@ -180,6 +257,8 @@ class _LSTMLayer(torch.autograd.Function):
                                  None if dh_seq is None else L.wptr(dh_seq), L.ptr(dh_last), L.ptr(dc_last), L.ptr(w_hh),
                                  L.wptr(dgp), L.ptr(db_ih), L.ptr(db_hh), 0, L.wptr(ws), ws_bytes, B, T, H, mode, st),
                     "vts_lstm_recurrent_bwd_planes")
+            recurrence_status.note("the backward recurrence (lstm_rec3p_bwd_kernel)", lib.vts_lstm_recurrent_bwd_status, ws,
+                                   ws_bytes, B, T, H)
             pws_bytes = lib.vts_lstm_planes_workspace_bytes(B, T, cin, H)
             pws = L.workspace(pws_bytes, dev)
             if dx is not None:
@@ -338,6 +417,8 @@ class _FeedForward(torch.autograd.Function):
                              L.ptr(w2), L.ptr(b2), L.ptr(keep), drop_p, seed, L.ptr(h),
                              None if mask is None else L.wptr(mask), L.ptr(y), M, K, Fh, _MODE, L.stream()),
                 "vts_ffn_fwd")
+        if FFN_TAPS is not None:
+            FFN_TAPS.append(h.detach())
         dropped = keep is not None or (bool(seed) and drop_p > 0)
         ctx.cfg = (M, K, Fh, 1.0 / (1.0 - drop_p) if dropped else 1.0)
         ctx.save_for_backward(x, w1, w2, h, mask)
@@ -455,6 +536,9 @@ def mlp_chain_usable(x, trunk, heads) -> bool:
         return False
     hd = heads[0][0].shape[0]
     if any(w.shape[0] != hd for w, _, _ in heads) or hd * len(heads) > 512 or (len(heads) > 1 and hd % 16):
+        return False
+    # the kernels read weight rows sixteen bytes at a time (a contiguous copy of a strided view is aligned again)
+    if any(w.is_contiguous() and w.data_ptr() % 16 for w, _, _ in list(trunk) + list(heads)):
         return False
     return all(a in (L.ACT_NONE, L.ACT_RELU, L.ACT_RELU_DROPOUT) for _, _, a in trunk)
 

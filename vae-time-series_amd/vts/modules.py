@@ -458,9 +458,13 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, z, noise: Noise = None):
         z = self.fc1(z, act=L.ACT_RELU)
+        if F.CHAIN_TAPS is not None:
+            F.CHAIN_TAPS["decoder.fc1"] = z.detach()
         site = _Site(noise, "dec_keep", self.training)
         keep = None if site.keep is None else site.keep.float()
         z = F.linear(z, self.fc2.weight, self.fc2.bias, L.ACT_RELU_DROPOUT, keep, TRANSFORMER_DROP_P, site.seed)
+        if F.CHAIN_TAPS is not None:
+            F.CHAIN_TAPS["decoder.fc2"] = z.detach()
         return self.final_fcn(self.out(z))
 
 

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .train import Adam, FlatParameters, forward_loss
+from .train import Adam, FlatParameters, forward_loss, raise_on_recurrence_timeout
 
 
 def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -63,6 +63,8 @@ class DataParallelTrainer:
         # instead of the mean of per-rank losses; they differ only through the mixtures' masked means, when
         # ranks hold different numbers of rows of a class.  The three-component loss keeps per-rank counts.
         self.exact_loss = bool(exact_loss) and self.distributed     # also with a 1-rank group: same code path
+        # how the 8 floats of loss statistics are summed over the ranks (in place); a test may substitute its own
+        self.reduce_loss_sums = lambda sums: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
         self.flat = FlatParameters(model)
         self.opt = (optimizer_factory or (lambda flat: Adam(flat, lr=lr)))(self.flat)
         self.buckets = plan_buckets(self.flat, max_buckets)
@@ -99,13 +101,14 @@ class DataParallelTrainer:
         return hook
 
     def step(self, x: torch.Tensor, y: torch.Tensor, noise=None, apply_update: bool = True) -> torch.Tensor:
+        from . import functional as F
+        F.recurrence_status.begin_step()
         self.opt.zero_grad()
         self._remaining = list(self._counts)
         self._pending = []
         self.events = []
         if self.exact_loss:
-            from . import functional as F
-            F.set_loss_reduction(lambda sums: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group), self.world)
+            F.set_loss_reduction(lambda sums: self.reduce_loss_sums(sums), self.world)
             try:
                 loss = forward_loss(self.model, x, y, noise)
             finally:
@@ -129,6 +132,7 @@ class DataParallelTrainer:
         else:
             self.flat.gather_grads()
         if apply_update:
+            raise_on_recurrence_timeout()       # (a rank that raises here leaves the others waiting in their next collective)
             self.opt.step(grad_scale=1.0 / self.world)
         return loss.detach()
 

@@ -168,10 +168,21 @@ def forward_loss(model: nn.Module, x: torch.Tensor, y: torch.Tensor,
     return model.loss_function(outs[0], y, *outs[1:])
 
 
+def raise_on_recurrence_timeout() -> None:
+    """Raises vts.RecurrenceTimeout if a cooperative recurrent kernel of this step timed out waiting for a peer
+    workgroup (its outputs are then NaN); called before the optimizer update so that the parameters stay intact.
+    Costs one host synchronisation in steps that ran such a kernel (bf16x3, hidden 256), nothing otherwise;
+    vts.set_status_checks(False) turns it off."""
+    from . import functional as F
+    F.recurrence_status.raise_on_timeout()
+
+
 def train_step(model: nn.Module, opt: Optional[Adam], x: torch.Tensor, y: torch.Tensor,
                noise: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """One optimisation step; returns the loss as a device scalar (no host sync).  With
     ``opt=None`` only forward + backward run (gradients are left in ``p.grad``)."""
+    from . import functional as F
+    F.recurrence_status.begin_step()
     if opt is not None:
         opt.zero_grad()
     else:
@@ -180,6 +191,7 @@ def train_step(model: nn.Module, opt: Optional[Adam], x: torch.Tensor, y: torch.
     loss = forward_loss(model, x, y, noise)
     loss.backward()
     if opt is not None:
+        raise_on_recurrence_timeout()
         opt.step()
     return loss.detach()
 
