@@ -3,7 +3,8 @@ through torch alone, optionally with libvts_hip.so loaded (and never called) or 
 memory map before it exits, so the crash report's addresses can be matched to libraries.
 
     rocprofv3 --kernel-trace --stats -d DIR -o p --output-format csv -- python3 tools/ubench/exit_probe.py MODE MAPS
-    MODE: torch | load | call
+    MODE: torch | load | call | coop | nocoop   (coop: a shape that takes the cooperative launches; nocoop: the same
+    shape with VTS_LSTM_CLUSTER_COOP=0 VTS_LSTM_PAIR_BWD=0 in the environment, i.e. plain launches only)
 """
 import os
 import sys
@@ -15,7 +16,7 @@ x = torch.randn(2048, 2048, device="cuda")
 for _ in range(5):
     x = x @ x * 1e-3
 torch.cuda.synchronize()
-if mode in ("load", "call"):
+if mode in ("load", "call", "coop", "nocoop"):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "vae-time-series_amd"))
     import vts
     from vts import _lib
@@ -24,6 +25,11 @@ if mode in ("load", "call"):
     if mode == "call":
         m = vts.LSTM(8, 64).cuda()
         m(torch.randn(16, 4, 8, device="cuda"))[1][0].sum().backward()
+        torch.cuda.synchronize()
+    if mode in ("coop", "nocoop"):
+        vts.set_mode("bf16x3")
+        m = vts.LSTM(8, 256).cuda()
+        m(torch.randn(128, 4, 8, device="cuda"))[1][0].sum().backward()
         torch.cuda.synchronize()
 with open("/proc/self/maps") as src, open(maps, "w") as dst:
     dst.write(src.read())

@@ -6,11 +6,13 @@ set -u
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/exitprobe
 mkdir -p "$out"
-for mode in torch load call; do
+for mode in torch load call coop nocoop; do
+  if [ $mode = nocoop ]; then export VTS_LSTM_CLUSTER_COOP=0 VTS_LSTM_PAIR_BWD=0; fi
   timeout -k 10 150 rocprofv3 --kernel-trace --stats -d "$out/$mode" -o p --output-format csv -- \
     python3 tools/ubench/exit_probe.py $mode "$out/$mode.maps" > "$out/$mode.out" 2> "$out/$mode.err"
   echo "$mode: exit $?" | tee -a "$out/summary.txt"
 done
+unset VTS_LSTM_CLUSTER_COOP VTS_LSTM_PAIR_BWD
 VTS_BENCH_DUMP_MAPS="$out/bench.maps" timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/bench" -o p --output-format csv -- \
   python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > "$out/bench.out" 2> "$out/bench.err"
 echo "bench: exit $?" | tee -a "$out/summary.txt"
