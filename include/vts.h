@@ -164,6 +164,26 @@ int vts_lstm_inproj_fwd_planes(const void* x_planes, int x_is_hseq, const float*
 int vts_lstm_recurrent_fwd_planes(float* gates, float* cells, float* hseq, void* h_planes, float* h_last, float* c_last,
                                   const float* w_hh, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
                                   int64_t H, int dtype_mode, vts_stream_t stream);
+/* vts_lstm_inproj_fwd_planes + vts_lstm_recurrent_fwd_planes as ONE kernel: the layer's forward pass with both weight
+ * matrices stationary on chip and the gate pre-activations never written to memory (per step
+ * gates_t = [x_t | h_{t-1}] . [W_ih | W_hh]^T + b_ih + b_hh; nn.LSTM's forward at vae-models/mixture-vae-DE.py:45,60 ;
+ * gpd-lstm-DE.py:18,27 ; gaussian-lstm-DE.py:16,28).  `gates` and `cells` receive what the backward entry points
+ * read (gate activations, cell states), h_planes the h sequence; hseq (fp32 [B,T,H]), h_last, c_last may be NULL.
+ * Taken for the shapes vts_lstm_fused_fwd_supported() accepts: those of vts_lstm_planes_supported() whose input is
+ * at most 64, 193..256 or 321..384 features wide and whose grid of B / 16 workgroups is resident at once; the
+ * workgroups wait for each other, so the launch has a status word like vts_lstm_recurrent_fwd
+ * (vts_lstm_fused_fwd_status: non-zero = a peer never showed up and the outputs are NaN).  Returns
+ * VTS_ERR_UNSUPPORTED when the runtime cannot guarantee a resident grid (or the stream is recording a graph):
+ * callers then run the two entry points above.  Same arithmetic as they (three bf16 MFMAs per fp32 product, fp32
+ * accumulation, the bias added first instead of last); results agree to the order of the fp32 sums. */
+int vts_lstm_fused_fwd_supported(int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode);
+size_t vts_lstm_fused_fwd_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H);
+int vts_lstm_fused_fwd_planes(const void* x_planes, int x_is_hseq, const float* w_ih, const float* b_ih,
+                              const float* b_hh, const float* w_hh, float* gates, float* cells, float* hseq,
+                              void* h_planes, float* h_last, float* c_last, void* workspace, size_t workspace_bytes,
+                              int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream);
+int vts_lstm_fused_fwd_status(const void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin,
+                              int64_t H, int32_t* status, vts_stream_t stream);
 /* vts_lstm_recurrent_bwd that writes the gate pre-activation gradients as planes (vts_lstm_planes_bytes(B, T, 4H, 0))
  * and leaves `gates` untouched */
 int vts_lstm_recurrent_bwd_planes(const float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,
@@ -199,6 +219,12 @@ void vts_debug_set_staged_bwd(int on);
  * start-up; taken for hidden 256, B a multiple of 32 and a grid that is resident at once).  Same results as the
  * one-workgroup kernels up to the order of the fp32 sums. */
 void vts_debug_set_pair_bwd(int on);
+/* Test hook, process-wide: member `member` (0..7) of every cluster of vts_lstm_fused_fwd_planes withholds its hand-off
+ * flags and the waits are cut short (vts_lstm_fused_fwd_status then reads non-zero); -1 = off (default). */
+void vts_debug_set_fused_fault(int member);
+/* Development switch, process-wide: on = 0 makes vts_lstm_fused_fwd_supported() answer 0, so that callers take the
+ * two-kernel forward path (default on, unless VTS_LSTM_FUSED_FWD=0 is set at start-up). */
+void vts_debug_set_fused_fwd(int on);
 /* Test hook, process-wide: member `member` (0 or 1) of every such pair withholds what it owes its peer and the
  * waits are cut short, so the timeout path (vts_lstm_recurrent_bwd_status) can be exercised; -1 = off (default). */
 void vts_debug_set_pair_fault(int member);

@@ -82,6 +82,13 @@ int vts_planes_wgrad(const void* dg_planes, const void* s_planes, int x_zero_slo
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
                        void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream);
 size_t vts_lstm_rec3c_bwd_flag_bytes(int B);
+bool vts_lstm_fused_usable(long B, long T, long Cin, long H);
+size_t vts_lstm_fused_image_bytes(long Cin);
+size_t vts_lstm_fused_flag_bytes(long B);
+void vts_lstm_fused_set_fault(int member);
+int vts_lstm_fused_fwd(const void* x_planes, int x_is_hseq, const float* w_ih, const float* b_ih, const float* b_hh,
+                       const float* w_hh, float* G, float* cseq, float* hseq, void* h_planes, float* hlast, float* clast,
+                       void* image, void* flags, unsigned* err, long B, long T, long Cin, hipStream_t stream);
 bool vts_lstm_rec3p_usable(int B, int T, int H);
 size_t vts_lstm_rec3p_xchg_bytes(int B);
 void vts_lstm_rec3p_set_fault(int member);
@@ -471,6 +478,55 @@ int vts_lstm_recurrent_fwd_planes(float* gates, float* cells, float* hseq, void*
   VTS_REQUIRE(h_planes && vts_aligned16(h_planes), "lstm_recurrent_fwd_planes: null or misaligned h_planes");
   return recurrent_fwd_impl(gates, cells, hseq, h_last, c_last, w_hh, workspace, workspace_bytes, B, T, H, dtype_mode,
                             h_planes, stream);
+}
+
+// ---- the layer's forward pass as one kernel (csrc/lstm_rec_fused.hip) ----
+static std::atomic<int> g_fused_fwd{[] { const char* e = getenv("VTS_LSTM_FUSED_FWD"); return (e && e[0] == '0') ? 0 : 1; }()};
+void vts_debug_set_fused_fwd(int on) { g_fused_fwd.store(on ? 1 : 0); }
+void vts_debug_set_fused_fault(int member) { vts_lstm_fused_set_fault(member); }
+int vts_lstm_fused_fwd_supported(int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode) {
+  if (g_fused_fwd.load() == 0 || !vts_lstm_planes_supported(B, T, Cin, H, dtype_mode)) return 0;
+  return vts_lstm_fused_usable((long)B, (long)T, (long)Cin, (long)H) ? 1 : 0;
+}
+// [weight image][flags][status word, 256 B]
+size_t vts_lstm_fused_fwd_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H) {
+  (void)T; (void)H;
+  return round256(vts_lstm_fused_image_bytes((long)Cin)) + round256(vts_lstm_fused_flag_bytes((long)B)) + 256;
+}
+static unsigned* fused_ws_status(void* workspace, int64_t B, int64_t Cin) {
+  return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + round256(vts_lstm_fused_image_bytes((long)Cin)) +
+                                     round256(vts_lstm_fused_flag_bytes((long)B)));
+}
+int vts_lstm_fused_fwd_planes(const void* x_planes, int x_is_hseq, const float* w_ih, const float* b_ih,
+                              const float* b_hh, const float* w_hh, float* gates, float* cells, float* hseq,
+                              void* h_planes, float* h_last, float* c_last, void* workspace, size_t workspace_bytes,
+                              int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream) {
+  VTS_PLANES_CHECK("lstm_fused_fwd_planes");
+  if (!vts_lstm_fused_fwd_supported(B, T, Cin, H, dtype_mode)) {
+    vts_set_error("lstm_fused_fwd_planes: not planned for B %ld, T %ld, Cin %ld (see vts_lstm_fused_fwd_supported)", (long)B,
+                  (long)T, (long)Cin);
+    return VTS_ERR_UNSUPPORTED;
+  }
+  VTS_REQUIRE(x_planes && w_ih && b_ih && b_hh && w_hh && gates && cells && h_planes && workspace, "lstm_fused_fwd_planes: null pointer");
+  VTS_REQUIRE(vts_aligned16(x_planes) && vts_aligned16(gates) && vts_aligned16(cells) && vts_aligned16(h_planes) &&
+                  vts_aligned16(workspace), "lstm_fused_fwd_planes: 16-byte alignment");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_fused_fwd_workspace_bytes(B, T, Cin, H), "lstm_fused_fwd_planes: workspace %zu B too small", workspace_bytes);
+  char* ws = reinterpret_cast<char*>(workspace);
+  return vts_lstm_fused_fwd(x_planes, x_is_hseq, w_ih, b_ih, b_hh, w_hh, gates, cells, hseq, h_planes, h_last, c_last, ws,
+                            ws + round256(vts_lstm_fused_image_bytes((long)Cin)), fused_ws_status(workspace, B, Cin), (long)B,
+                            (long)T, (long)Cin, reinterpret_cast<hipStream_t>(stream));
+}
+int vts_lstm_fused_fwd_status(const void* workspace, size_t workspace_bytes, int64_t B, int64_t T, int64_t Cin,
+                              int64_t H, int32_t* status, vts_stream_t stream) {
+  VTS_RC(lstm_check(B, T, Cin, H));
+  VTS_REQUIRE(workspace && status, "lstm_fused_fwd_status: null pointer");
+  VTS_REQUIRE(workspace_bytes >= vts_lstm_fused_fwd_workspace_bytes(B, T, Cin, H), "lstm_fused_fwd_status: workspace %zu B too small", workspace_bytes);
+  if (hipMemcpyAsync(status, fused_ws_status(const_cast<void*>(workspace), B, Cin), sizeof(int32_t), hipMemcpyDeviceToDevice,
+                     reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+    vts_set_error("lstm_fused_fwd_status: copy failed");
+    return VTS_ERR_HIP;
+  }
+  return VTS_OK;
 }
 
 int vts_lstm_recurrent_bwd_planes(const float* gates, const float* cells, const float* dh_seq_t16, const float* dh_last,

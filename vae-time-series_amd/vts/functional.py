@@ -184,17 +184,34 @@ class _LSTMLayer(torch.autograd.Function):
                                      H, mode, st), "vts_lstm_planes_from_rows")
             else:
                 xp = inp
-            pws_bytes = lib.vts_lstm_planes_workspace_bytes(B, T, cin, H)
-            pws = L.workspace(pws_bytes, dev)
-            L.check(L.timer.call("lstm_inproj_fwd", lib.vts_lstm_inproj_fwd_planes, L.wptr(xp), 0 if cfg.first else 1,
-                                 L.ptr(w_ih), L.ptr(b_ih), L.ptr(b_hh), L.wptr(gates), L.wptr(pws), pws_bytes, B, T, cin,
-                                 H, mode, st), "vts_lstm_inproj_fwd_planes")
             hp = torch.empty(lib.vts_lstm_planes_bytes(B, T, H, 1) // 4, device=dev, dtype=torch.float32)
-            L.check(L.timer.call("lstm_recurrent_fwd", lib.vts_lstm_recurrent_fwd_planes, L.wptr(gates), L.wptr(cells),
-                                 L.ptr(hseq), L.wptr(hp), L.ptr(h_last), L.ptr(c_last), L.ptr(w_hh), L.wptr(ws), ws_bytes,
-                                 B, T, H, mode, st), "vts_lstm_recurrent_fwd_planes")
-            recurrence_status.note("the forward recurrence (lstm_rec3c_fwd_kernel)", lib.vts_lstm_recurrent_fwd_status, ws,
-                                   ws_bytes, B, T, H)
+            fused = False
+            if lib.vts_lstm_fused_fwd_supported(B, T, cin, H, mode):
+                # the whole forward pass of the layer in one kernel; refused (code 3: the runtime will not promise a
+                # resident grid, or the stream is recording a graph) -> the two kernels below
+                fws_bytes = lib.vts_lstm_fused_fwd_workspace_bytes(B, T, cin, H)
+                fws = L.workspace(fws_bytes, dev)
+                rc = L.timer.call("lstm_fused_fwd", lib.vts_lstm_fused_fwd_planes, L.wptr(xp), 0 if cfg.first else 1,
+                                  L.ptr(w_ih), L.ptr(b_ih), L.ptr(b_hh), L.ptr(w_hh), L.wptr(gates), L.wptr(cells),
+                                  L.ptr(hseq), L.wptr(hp), L.ptr(h_last), L.ptr(c_last), L.wptr(fws), fws_bytes, B, T,
+                                  cin, H, mode, st)
+                if rc != 3:
+                    L.check(rc, "vts_lstm_fused_fwd_planes")
+                    fused = True
+                    recurrence_status.note("the fused forward pass (lstm_fused_fwd_kernel)",
+                                           lambda w, wb, b_, t_, h_, out, s_: lib.vts_lstm_fused_fwd_status(w, wb, b_, t_, cin, h_, out, s_),
+                                           fws, fws_bytes, B, T, H)
+            if not fused:
+                pws_bytes = lib.vts_lstm_planes_workspace_bytes(B, T, cin, H)
+                pws = L.workspace(pws_bytes, dev)
+                L.check(L.timer.call("lstm_inproj_fwd", lib.vts_lstm_inproj_fwd_planes, L.wptr(xp), 0 if cfg.first else 1,
+                                     L.ptr(w_ih), L.ptr(b_ih), L.ptr(b_hh), L.wptr(gates), L.wptr(pws), pws_bytes, B, T, cin,
+                                     H, mode, st), "vts_lstm_inproj_fwd_planes")
+                L.check(L.timer.call("lstm_recurrent_fwd", lib.vts_lstm_recurrent_fwd_planes, L.wptr(gates), L.wptr(cells),
+                                     L.ptr(hseq), L.wptr(hp), L.ptr(h_last), L.ptr(c_last), L.ptr(w_hh), L.wptr(ws), ws_bytes,
+                                     B, T, H, mode, st), "vts_lstm_recurrent_fwd_planes")
+                recurrence_status.note("the forward recurrence (lstm_rec3c_fwd_kernel)", lib.vts_lstm_recurrent_fwd_status, ws,
+                                       ws_bytes, B, T, H)
             ctx.save_for_backward(xp, gates, cells, hp, w_ih, w_hh)
         else:
             x_rows = inp if cfg.first else inp   # rows either way; only the first B windows of a padded tensor are read
