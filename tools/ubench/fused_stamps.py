@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vae-time-series_amd"))
 import torch
 from vts import _lib as L
-stamped = os.path.join(ROOT, "tools", "ubench", "libvts_fstamp.so")
+stamped = os.environ.get("VTS_STAMP_LIB") or os.path.join(ROOT, "tools", "ubench", "libvts_fstamp.so")
 if os.path.exists(stamped) and os.environ.get("VTS_NO_STAMP") != "1":
     L.LIB_PATH = stamped
 lib = L.load()

@@ -49,6 +49,13 @@ constexpr int F_STAGE = FRT * 2 * 16 * 16;         // per wave: [window tile][pl
 constexpr int F_LDS = 2 * F_HALF + 4 * F_STAGE;    // 144 KiB
 constexpr int F_FLAG_STRIDE = 32;                  // uint32 words between flags (one 128-byte line each)
 constexpr int F_SC1 = 16;                          // cache-policy operand of the buffer builtins: agent scope
+#ifndef VTS_F_NT
+#define VTS_F_NT 0
+#endif
+constexpr int F_BULK = VTS_F_NT;                   // ... of the saved tensors' stores (2 = non-temporal)
+#ifndef VTS_F_STAGGER
+#define VTS_F_STAGGER 0
+#endif
 
 template <class F, int... I>
 __device__ __forceinline__ void fstatic_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -67,6 +74,12 @@ __device__ __forceinline__ float swap8(float v) {
 }
 __device__ __forceinline__ float fswap1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+// one dword to LDS at addr + OFF, OFF in the instruction's offset field
+template <int OFF>
+__device__ __forceinline__ void lds_write_b32_at(unsigned addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 
 // gate (0 i, 1 f, 2 g, 3 o) of column r of a wave's column tile ct
@@ -122,6 +135,10 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
   constexpr int JT = FH / 16;
   constexpr int NXB = (KX + 3) / 4;               // blocks of the input part
   constexpr int NF = (KX + 8) * 4;
+#ifndef VTS_F_XACC8
+#define VTS_F_XACC8 1
+#endif
+  constexpr int FX_IN_ACC = KX > 8 ? KX - 8 : (KX == 8 ? VTS_F_XACC8 : 0);   // input k-steps kept in accumulator registers
   extern __shared__ __attribute__((aligned(16))) unsigned char smemf[];
   __shared__ int dead;
   const int tid = threadIdx.x;
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          if (KX > 8 && ks < KX - 8) asm volatile("" : "+a"(wx[ks][ct][p]));
+          if (ks < FX_IN_ACC) asm volatile("" : "+a"(wx[ks][ct][p]));
           else asm volatile("" : "+v"(wx[ks][ct][p]));
         }
 #pragma unroll
@@ -228,6 +245,13 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
   auto land = [&] {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
+  auto land8 = [&] {       // ... when the eight youngest accesses in flight are stores
+#ifdef VTS_F_SPREAD
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    land();
+#endif
+  };
 
   // ---- slot 0 of this member's column block: the zero state; flag 1 = "slot 0 is there"
 #pragma unroll
@@ -241,6 +265,11 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
   if (tid == 0 && c != mute_member)
     __hip_atomic_store(fq + c * F_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+  if (VTS_F_STAGGER > 0) {
+    // clusters start a fraction of a step apart, so that their bursts of stores do not meet in the memory system
+    const long long t0 = clock64();
+    while (clock64() - t0 < (long long)(q & 3) * VTS_F_STAGGER) __builtin_amdgcn_s_sleep(8);
+  }
   f32x4 acc[FRT][2];
   float cst[FRT][2];
 #pragma unroll
@@ -313,19 +342,34 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
                                                                          FRT * T * (4 * JT) * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(cseq + (long)q * FRT * T * JT * 256, 0,
                                                                          FRT * T * JT * 1024, 0x00020000);
+#ifdef VTS_F_CONTIG       // timing-only ablation (wrong results): every store instruction writes one contiguous KiB
+  const int gv0 = ((wave & 1) * 2 * JT + jt) * 1024 + lane * 16, gv1 = (((wave & 1) * 2 + 1) * JT + jt) * 1024 + lane * 16;
+  const int cv = jt * 1024 + (wave & 1) * 512 + lane * 8;
+#else
   const int gv0 = (gate0 * JT + jt) * 1024 + (g * 16 + colb) * 16, gv1 = (gate1 * JT + jt) * 1024 + (g * 16 + colb) * 16;
   const int cv = jt * 1024 + (g * 16 + colb) * 16 + (lo8 ? 0 : 8);
+#endif
   auto store_piece = [&](int t, int rt, int piece) {
+#ifdef VTS_F_NOSTORE      // timing-only ablation: what the saved tensors' stores cost
+    return;
+#endif
     const int bt_t = rt * T + t;
     if (piece < 2)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fvec4, acc[rt][piece]), grsrc, piece == 0 ? gv0 : gv1,
-                                             bt_t * (4 * JT * 1024), 0);
+                                             bt_t * (4 * JT * 1024), F_BULK);
     else
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fvu2, float2{cst[rt][0], cst[rt][1]}), crsrc, cv, bt_t * (JT * 1024), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fvu2, float2{cst[rt][0], cst[rt][1]}), crsrc, cv, bt_t * (JT * 1024), F_BULK);
   };
   // activations in place, swap, cell update of window tile rt for this lane's two rows (4 g + (lo8 ? 0 : 2) + {0, 1}),
   // h to the staging tile
-  auto cell_rt = [&](int rt) {
+  // (the staging address is one register per lane plus a constant per (window tile, row): written as compile-time
+  // offsets of the LDS instruction; sixteen separate address registers did not fit and were reloaded from scratch
+  // memory in the middle of the step, each reload waiting for every DMA load in flight)
+  const unsigned stage_lane = gp::lds_addr(reinterpret_cast<const char*>(stage)) + ((hl & 1) ? 256 : 0) +
+                              (4 * g + (lo8 ? 0 : 2)) * 16 + (hl & ~1) * 2;
+  const int pub_lane = (int)(((long)(lane >> 5) * hp.ts * hp.ncb * 2 + ((lane >> 4) & 1)) * gp::TILE_B) + gp::slot(wave, lane & 15) * 16;
+  auto cell_rt = [&](auto rt_c) {
+    constexpr int rt = decltype(rt_c)::value;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[rt][0][e] = am * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ak * acc[rt][0][e])) + aa;
@@ -336,8 +380,8 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
     rcv[1] = swap8(lo8 ? acc[rt][0][3] : acc[rt][0][1]);
     rcv[2] = swap8(lo8 ? acc[rt][1][2] : acc[rt][1][0]);
     rcv[3] = swap8(lo8 ? acc[rt][1][3] : acc[rt][1][1]);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    fstatic_for<2>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
       const float gi = lo8 ? acc[rt][0][k] : rcv[k];
       const float gg = lo8 ? rcv[k] : acc[rt][0][k + 2];
       const float gf = lo8 ? acc[rt][1][k] : rcv[2 + k];
@@ -345,14 +389,13 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
       const float cnew = gf * cst[rt][k] + gi * gg;
       cst[rt][k] = cnew;
       const float h = go * fast_tanh(cnew);
-      const int row = 4 * g + (lo8 ? 0 : 2) + k;
       // h -> staging as bf16 head / tail pairs: the even lane of a pair writes the two heads, the odd one the tails
       const float other = fswap1(h);
       const bool odd = hl & 1;
       unsigned hi, lo;
       split2(odd ? other : h, odd ? h : other, hi, lo);
-      *reinterpret_cast<unsigned*>(stage + ((rt * 2 + (odd ? 1 : 0)) * 16 + row) * 16 + (hl & ~1) * 2) = odd ? lo : hi;
-    }
+      lds_write_b32_at<rt * 512 + k * 16>(stage_lane, odd ? lo : hi);
+    });
   };
 
 #ifdef VTS_F_STAMP
@@ -370,10 +413,12 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
     FSTAMP(0);
     // The saved tensors of the step before leave now, behind the hand-off: a pair's pieces before that pair's
     // accumulators are set to the bias again - pair 0's here, pair rp + 1's between the groups of pair rp.
+#ifndef VTS_F_SPREAD
     if (t > 0) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) store_piece(t - 1, i / 3, i % 3);
     }
+#endif
     FSTAMP(12);
     bool gone = false;
     fstatic_for<NXB>([&](auto xb_c) {
@@ -384,7 +429,7 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
       constexpr int SPER = (6 + NKS - 1) / NKS;      // store pieces of the next pair per group
       static_assert(NG * PER == 16, "operand tiles divide over the groups");
       if (gone) return;
-      if (xb > 0) land();
+      if (xb > 0) land8();
       FSTAMP(2 * xb);
       if (last) {
         // h_{t-1} is slot t: every member's flag must have reached t + 1 before its tiles are asked for
@@ -410,6 +455,21 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
       compute(std::false_type{}, xb_c, half, [&](auto gi_c) {
         constexpr int gi = decltype(gi_c)::value;
         constexpr int rp = gi / NKS, ksl = gi % NKS;
+#ifdef VTS_F_SPREAD     // timing-only experiment (KX = 8): loads in the first half of a block, one store per group behind them
+        if (gi < 8) {
+#pragma unroll
+          for (int n = 2 * gi; n < 2 * gi + 2; ++n) {
+            if (last) issue_h_tile(t - 1, 0, half ^ 1, n);
+            else issue_x_tile(t, xb + 1, half ^ 1, n);
+          }
+        } else if (t > 0) {
+          store_piece(t - 1, (xb * 8 + gi - 8) / 3, (xb * 8 + gi - 8) % 3);
+        }
+        if (xb == 0 && ksl == 0) {
+          acc[2 * rp][0] = acc[2 * rp + 1][0] = f32x4{bias0, bias0, bias0, bias0};
+          acc[2 * rp][1] = acc[2 * rp + 1][1] = f32x4{bias1, bias1, bias1, bias1};
+        }
+#else
 #pragma unroll
         for (int n = gi * PER; n < (gi + 1) * PER; ++n) {
           if (last) issue_h_tile(t - 1, 0, half ^ 1, n);
@@ -425,32 +485,43 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
             for (int i = ksl * SPER; i < (ksl + 1) * SPER && i < 6; ++i) store_piece(t - 1, 2 * (rp + 1) + i / 3, i % 3);
           }
         }
+#endif
       });
       FSTAMP(2 * xb + 1);
       half ^= 1;
     });
     if (gone) break;
-    land();
+    land8();
     FSTAMP(6);
     compute(std::true_type{}, std::integral_constant<int, 0>{}, half, [&](auto gi_c) {
+#ifdef VTS_F_SPREAD
+      constexpr int gi = decltype(gi_c)::value;
+      if (gi < 8) {
+        issue_h_tile(t - 1, 1, half ^ 1, 2 * gi);
+        issue_h_tile(t - 1, 1, half ^ 1, 2 * gi + 1);
+      } else if (t > 0) {
+        store_piece(t - 1, (16 + gi - 8) / 3, (16 + gi - 8) % 3);
+      }
+#else
       issue_h_tile(t - 1, 1, half ^ 1, decltype(gi_c)::value);
+#endif
     });
     FSTAMP(7);
     half ^= 1;
-    land();
+    land8();
     FSTAMP(8);
     // the last block: a pair whose products are complete goes through its cell update between the groups of the next
     compute(std::true_type{}, std::integral_constant<int, 1>{}, half, [&](auto gi_c) {
       constexpr int gi = decltype(gi_c)::value;
       constexpr int rp = gi / 4, ksl = gi % 4;
       issue_x_tile(t + 1 < T ? t + 1 : t, 0, half ^ 1, gi);      // (the last step fetches its own tiles again: no branch here)
-      if (rp > 0 && ksl == 0) cell_rt(2 * (rp - 1));
-      if (rp > 0 && ksl == 2) cell_rt(2 * (rp - 1) + 1);
+      if constexpr (rp > 0 && ksl == 0) cell_rt(std::integral_constant<int, 2 * (rp > 0 ? rp - 1 : 0)>{});
+      if constexpr (rp > 0 && ksl == 2) cell_rt(std::integral_constant<int, 2 * (rp > 0 ? rp - 1 : 0) + 1>{});
     });
     FSTAMP(9);
     half ^= 1;
-    cell_rt(FRT - 2);
-    cell_rt(FRT - 1);
+    cell_rt(std::integral_constant<int, FRT - 2>{});
+    cell_rt(std::integral_constant<int, FRT - 1>{});
     FSTAMP(10);
     // ---- publish h_t: this wave's k-group (eight units = one 16-byte slot per row) of column block c
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -458,11 +529,11 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int s = i * 64 + lane;                 // [window tile 8][plane 2][row 16]
-      const int rt = s >> 5, p = (s >> 4) & 1, row = s & 15;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + s * 16);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fvec4, v), hrsrc, hp_block(rt, t, c, p) + gp::slot(wave, row) * 16,
-                                             0, F_SC1);
+      // staging slot i * 64 + lane = [window tile 2 i + (lane >> 5)][plane (lane >> 4) & 1][row lane & 15]: the lane's
+      // part of the address never changes, the (i, step) part is the scalar offset
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + (i * 64 + lane) * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fvec4, v), hrsrc, pub_lane,
+                                             (int)(((long)(2 * i) * hp.ts + hp.t0 + t) * hp.ncb + c) * (2 * gp::TILE_B), F_SC1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
