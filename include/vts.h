@@ -175,8 +175,14 @@ int vts_lstm_recurrent_fwd_planes(float* gates, float* cells, float* hseq, void*
  * (vts_lstm_fused_fwd_status: non-zero = a peer never showed up and the outputs are NaN).  Returns
  * VTS_ERR_UNSUPPORTED when the runtime cannot guarantee a resident grid (or the stream is recording a graph):
  * callers then run the two entry points above.  Same arithmetic as they (three bf16 MFMAs per fp32 product, fp32
- * accumulation, the bias added first instead of last); results agree to the order of the fp32 sums. */
+ * accumulation, the bias added first instead of last); results agree to the order of the fp32 sums.
+ * vts_lstm_fused_fwd_preferred() says whether callers that have the choice should take this entry point: 0 unless
+ * VTS_LSTM_FUSED_FWD=1 was set at start-up or vts_debug_set_fused_fwd(1) was called - measured at 4096 x 96 windows
+ * the one kernel is level with the two (1.55-1.7 ms against 1.53 ms for a 256-wide input, 2.0-2.3 ms against
+ * 1.75 ms for a 370-wide one: the saved tensors' stores, 80 KiB per compute unit and step, hold up its only wave
+ * per SIMD), so the Python face keeps the two-kernel path by default. */
 int vts_lstm_fused_fwd_supported(int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode);
+int vts_lstm_fused_fwd_preferred(void);
 size_t vts_lstm_fused_fwd_workspace_bytes(int64_t B, int64_t T, int64_t Cin, int64_t H);
 int vts_lstm_fused_fwd_planes(const void* x_planes, int x_is_hseq, const float* w_ih, const float* b_ih,
                               const float* b_hh, const float* w_hh, float* gates, float* cells, float* hseq,
@@ -222,8 +228,8 @@ void vts_debug_set_pair_bwd(int on);
 /* Test hook, process-wide: member `member` (0..7) of every cluster of vts_lstm_fused_fwd_planes withholds its hand-off
  * flags and the waits are cut short (vts_lstm_fused_fwd_status then reads non-zero); -1 = off (default). */
 void vts_debug_set_fused_fault(int member);
-/* Development switch, process-wide: on = 0 makes vts_lstm_fused_fwd_supported() answer 0, so that callers take the
- * two-kernel forward path (default on, unless VTS_LSTM_FUSED_FWD=0 is set at start-up). */
+/* Development switch, process-wide: what vts_lstm_fused_fwd_preferred() answers (default 0, or 1 when
+ * VTS_LSTM_FUSED_FWD=1 is set at start-up). */
 void vts_debug_set_fused_fwd(int on);
 /* Test hook, process-wide: member `member` (0 or 1) of every such pair withholds what it owes its peer and the
  * waits are cut short, so the timeout path (vts_lstm_recurrent_bwd_status) can be exercised; -1 = off (default). */

@@ -172,3 +172,82 @@ def test_pair_backward_with_a_missing_peer():
     again = _pair_case(-1)
     for k in good:
         assert torch.equal(good[k], again[k]), k
+
+
+@pytest.fixture()
+def fused_forward():
+    """The layer's forward pass as one kernel (vts_lstm_fused_fwd_planes) instead of input projection + recurrence."""
+    from vts import _lib
+    lib = _lib.load()
+    lib.vts_debug_set_fused_fwd(1)
+    yield lib
+    lib.vts_debug_set_fused_fwd(0)
+    lib.vts_debug_set_fused_fault(-1)
+
+
+@pytest.mark.parametrize("B,T,C,H,layers", [
+    (128, 2, 8, 256, 1),      # one cluster; input planes two column blocks wide
+    (128, 6, 370, 256, 3),    # twelve column blocks (first layer), eight (the layers above it)
+    (1024, 8, 256, 256, 2),   # eight clusters, eight column blocks in both layers
+])
+@pytest.mark.parametrize("need_output", [True, False])
+def test_fused_forward_matches_torch_lstm(fused_forward, B, T, C, H, layers, need_output):
+    """Outputs, final states and every gradient (the backward kernels read the gate activations and cell states the
+    fused kernel saved) against torch's CPU nn.LSTM, at the bound of the two-kernel path."""
+    lib = fused_forward
+    assert lib.vts_lstm_fused_fwd_supported(B, T, C, H, 1)
+    import vts
+    vts.recurrence_status.begin_step()
+    _run_plane_case(B, T, C, H, layers, need_output)
+    names = [n for n, _ in vts.recurrence_status.read()]
+    assert sum("fused forward" in n for n in names) == layers, names      # ... and the fused kernel is what ran
+
+
+def test_fused_forward_against_the_two_kernel_path():
+    """Same inputs through both forward paths: final states agree to 1e-5 (the fused kernel hands h on as a bf16 head
+    plus tail, 2^-17 relative, and sums in another order), and a width it is not built for (100 features) takes the
+    two-kernel path without complaint."""
+    import vts
+    from vts import _lib
+    lib = _lib.load()
+    dev = _dev()
+    torch.manual_seed(21)
+    lstm = vts.LSTM(256, 256, num_layers=2).to(dev)
+    x = torch.randn(256, 10, 256, device=dev)
+    _, (h0, c0) = lstm(x, need_output=False)
+    lib.vts_debug_set_fused_fwd(1)
+    try:
+        _, (h1, c1) = lstm(x, need_output=False)
+        assert not lib.vts_lstm_fused_fwd_supported(256, 10, 100, 256, 1)
+        odd = vts.LSTM(100, 256).to(dev)
+        _, (h2, _) = odd(torch.randn(256, 10, 100, device=dev), need_output=False)
+        assert torch.isfinite(h2).all()
+    finally:
+        lib.vts_debug_set_fused_fwd(0)
+    assert l2_rel(h1, h0) < 1e-5 and l2_rel(c1, c0) < 1e-5
+
+
+def test_fused_forward_with_a_missing_peer(fused_forward):
+    """A member that never raises its flags: the launch ends with NaN outputs and a non-zero status word, and
+    vts.recurrence_status names the kernel; the next launch is clean."""
+    import vts
+    lib = fused_forward
+    dev = _dev()
+    torch.manual_seed(4)
+    lstm = vts.LSTM(8, 256).to(dev)
+    x = torch.randn(128, 4, 8, device=dev)
+    vts.recurrence_status.begin_step()
+    _, (good, _) = lstm(x, need_output=False)
+    assert all(v == 0 for _, v in vts.recurrence_status.read())
+    lib.vts_debug_set_fused_fault(3)
+    vts.recurrence_status.begin_step()
+    _, (bad, _) = lstm(x, need_output=False)
+    torch.cuda.synchronize()
+    lib.vts_debug_set_fused_fault(-1)
+    st = vts.recurrence_status.read()
+    assert any("fused forward" in n and v != 0 for n, v in st), st
+    assert torch.isnan(bad).any()
+    vts.recurrence_status.begin_step()
+    _, (again, _) = lstm(x, need_output=False)
+    assert torch.equal(again, good)
+    assert all(v == 0 for _, v in vts.recurrence_status.read())

@@ -245,13 +245,6 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
   auto land = [&] {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
-  auto land8 = [&] {       // ... when the eight youngest accesses in flight are stores
-#ifdef VTS_F_SPREAD
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    land();
-#endif
-  };
 
   // ---- slot 0 of this member's column block: the zero state; flag 1 = "slot 0 is there"
 #pragma unroll
@@ -342,13 +335,8 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
                                                                          FRT * T * (4 * JT) * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(cseq + (long)q * FRT * T * JT * 256, 0,
                                                                          FRT * T * JT * 1024, 0x00020000);
-#ifdef VTS_F_CONTIG       // timing-only ablation (wrong results): every store instruction writes one contiguous KiB
-  const int gv0 = ((wave & 1) * 2 * JT + jt) * 1024 + lane * 16, gv1 = (((wave & 1) * 2 + 1) * JT + jt) * 1024 + lane * 16;
-  const int cv = jt * 1024 + (wave & 1) * 512 + lane * 8;
-#else
   const int gv0 = (gate0 * JT + jt) * 1024 + (g * 16 + colb) * 16, gv1 = (gate1 * JT + jt) * 1024 + (g * 16 + colb) * 16;
   const int cv = jt * 1024 + (g * 16 + colb) * 16 + (lo8 ? 0 : 8);
-#endif
   auto store_piece = [&](int t, int rt, int piece) {
 #ifdef VTS_F_NOSTORE      // timing-only ablation: what the saved tensors' stores cost
     return;
@@ -413,12 +401,10 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
     FSTAMP(0);
     // The saved tensors of the step before leave now, behind the hand-off: a pair's pieces before that pair's
     // accumulators are set to the bias again - pair 0's here, pair rp + 1's between the groups of pair rp.
-#ifndef VTS_F_SPREAD
     if (t > 0) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) store_piece(t - 1, i / 3, i % 3);
     }
-#endif
     FSTAMP(12);
     bool gone = false;
     fstatic_for<NXB>([&](auto xb_c) {
@@ -429,7 +415,7 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
       constexpr int SPER = (6 + NKS - 1) / NKS;      // store pieces of the next pair per group
       static_assert(NG * PER == 16, "operand tiles divide over the groups");
       if (gone) return;
-      if (xb > 0) land8();
+      if (xb > 0) land();
       FSTAMP(2 * xb);
       if (last) {
         // h_{t-1} is slot t: every member's flag must have reached t + 1 before its tiles are asked for
@@ -455,21 +441,6 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
       compute(std::false_type{}, xb_c, half, [&](auto gi_c) {
         constexpr int gi = decltype(gi_c)::value;
         constexpr int rp = gi / NKS, ksl = gi % NKS;
-#ifdef VTS_F_SPREAD     // timing-only experiment (KX = 8): loads in the first half of a block, one store per group behind them
-        if (gi < 8) {
-#pragma unroll
-          for (int n = 2 * gi; n < 2 * gi + 2; ++n) {
-            if (last) issue_h_tile(t - 1, 0, half ^ 1, n);
-            else issue_x_tile(t, xb + 1, half ^ 1, n);
-          }
-        } else if (t > 0) {
-          store_piece(t - 1, (xb * 8 + gi - 8) / 3, (xb * 8 + gi - 8) % 3);
-        }
-        if (xb == 0 && ksl == 0) {
-          acc[2 * rp][0] = acc[2 * rp + 1][0] = f32x4{bias0, bias0, bias0, bias0};
-          acc[2 * rp][1] = acc[2 * rp + 1][1] = f32x4{bias1, bias1, bias1, bias1};
-        }
-#else
 #pragma unroll
         for (int n = gi * PER; n < (gi + 1) * PER; ++n) {
           if (last) issue_h_tile(t - 1, 0, half ^ 1, n);
@@ -485,30 +456,19 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(
             for (int i = ksl * SPER; i < (ksl + 1) * SPER && i < 6; ++i) store_piece(t - 1, 2 * (rp + 1) + i / 3, i % 3);
           }
         }
-#endif
       });
       FSTAMP(2 * xb + 1);
       half ^= 1;
     });
     if (gone) break;
-    land8();
+    land();
     FSTAMP(6);
     compute(std::true_type{}, std::integral_constant<int, 0>{}, half, [&](auto gi_c) {
-#ifdef VTS_F_SPREAD
-      constexpr int gi = decltype(gi_c)::value;
-      if (gi < 8) {
-        issue_h_tile(t - 1, 1, half ^ 1, 2 * gi);
-        issue_h_tile(t - 1, 1, half ^ 1, 2 * gi + 1);
-      } else if (t > 0) {
-        store_piece(t - 1, (16 + gi - 8) / 3, (16 + gi - 8) % 3);
-      }
-#else
       issue_h_tile(t - 1, 1, half ^ 1, decltype(gi_c)::value);
-#endif
     });
     FSTAMP(7);
     half ^= 1;
-    land8();
+    land();
     FSTAMP(8);
     // the last block: a pair whose products are complete goes through its cell update between the groups of the next
     compute(std::true_type{}, std::integral_constant<int, 1>{}, half, [&](auto gi_c) {

@@ -481,11 +481,12 @@ int vts_lstm_recurrent_fwd_planes(float* gates, float* cells, float* hseq, void*
 }
 
 // ---- the layer's forward pass as one kernel (csrc/lstm_rec_fused.hip) ----
-static std::atomic<int> g_fused_fwd{[] { const char* e = getenv("VTS_LSTM_FUSED_FWD"); return (e && e[0] == '0') ? 0 : 1; }()};
+static std::atomic<int> g_fused_fwd{[] { const char* e = getenv("VTS_LSTM_FUSED_FWD"); return (e && e[0] == '1') ? 1 : 0; }()};
 void vts_debug_set_fused_fwd(int on) { g_fused_fwd.store(on ? 1 : 0); }
 void vts_debug_set_fused_fault(int member) { vts_lstm_fused_set_fault(member); }
+int vts_lstm_fused_fwd_preferred(void) { return g_fused_fwd.load(); }
 int vts_lstm_fused_fwd_supported(int64_t B, int64_t T, int64_t Cin, int64_t H, int dtype_mode) {
-  if (g_fused_fwd.load() == 0 || !vts_lstm_planes_supported(B, T, Cin, H, dtype_mode)) return 0;
+  if (!vts_lstm_planes_supported(B, T, Cin, H, dtype_mode)) return 0;
   return vts_lstm_fused_usable((long)B, (long)T, (long)Cin, (long)H) ? 1 : 0;
 }
 // [weight image][flags][status word, 256 B]

@@ -71,6 +71,7 @@ SIGNATURES = {
                                           _ptr]),
     "vts_lstm_recurrent_fwd_planes": (_int, [_ptr] * 7 + [_ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_fused_fwd_supported": (_int, [_i64, _i64, _i64, _i64, _int]),
+    "vts_lstm_fused_fwd_preferred": (_int, []),
     "vts_lstm_fused_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "vts_lstm_fused_fwd_planes": (_int, [_ptr, _int] + [_ptr] * 10 + [_ptr, _sz, _i64, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_fused_fwd_status": (_int, [_ptr, _sz, _i64, _i64, _i64, _i64, _ptr, _ptr]),

@@ -186,7 +186,7 @@ class _LSTMLayer(torch.autograd.Function):
                 xp = inp
             hp = torch.empty(lib.vts_lstm_planes_bytes(B, T, H, 1) // 4, device=dev, dtype=torch.float32)
             fused = False
-            if lib.vts_lstm_fused_fwd_supported(B, T, cin, H, mode):
+            if lib.vts_lstm_fused_fwd_preferred() and lib.vts_lstm_fused_fwd_supported(B, T, cin, H, mode):
                 # the whole forward pass of the layer in one kernel; refused (code 3: the runtime will not promise a
                 # resident grid, or the stream is recording a graph) -> the two kernels below
                 fws_bytes = lib.vts_lstm_fused_fwd_workspace_bytes(B, T, cin, H)
