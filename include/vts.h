@@ -444,6 +444,19 @@ int vts_ffn_bwd(const float* dy, const float* x, int64_t ldx, const float* w1, c
                 const float* hidden, const void* mask, float drop_scale, float* dx, int64_t lddx, float* dw1,
                 float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, int64_t M, int64_t d,
                 int64_t F, int dtype_mode, vts_stream_t stream);
+/* The block's backward pass without any [M, F] tensor in memory: where vts_ffn_recompute_supported() answers 1
+ * (bf16x3 mode, d = 64, F a multiple of 256, the shapes the fused kernels take) vts_ffn_fwd accepts hidden = NULL
+ * and writes only the packed mask, and vts_ffn_bwd_recompute works hidden and the pre-activation gradient out
+ * again from x, dy, the weights and that mask, tile by tile, inside the kernel that accumulates dw1 and dw2
+ * (six products instead of four; 12 bytes per hidden element less HBM traffic, forward and backward together).
+ * Same arguments as vts_ffn_bwd with b1 in place of hidden; dx is required.  nn.TransformerEncoderLayer's
+ * linear1 / relu / dropout / linear2 at vae-models/mixture-vae-transformer.py:39. */
+int vts_ffn_recompute_supported(const float* x, int64_t ldx, int64_t M, int64_t d, int64_t F, int dtype_mode);
+size_t vts_ffn_bwd_recompute_workspace_bytes(int64_t M, int64_t d, int64_t F);
+int vts_ffn_bwd_recompute(const float* dy, const float* x, int64_t ldx, const float* w1, const float* b1,
+                          const float* w2, const void* mask, float drop_scale, float* dx, int64_t lddx, float* dw1,
+                          float* db1, float* dw2, float* db2, void* workspace, size_t workspace_bytes, int64_t M,
+                          int64_t d, int64_t F, int dtype_mode, vts_stream_t stream);
 /* out = residual + dropout(x) (residual NULL = 0): x + dropout1(sa) and x + dropout2(ff) of the layer */
 int vts_dropout_add_fwd(const float* residual, const float* x, const uint8_t* keep, float drop_p, uint64_t seed,
                         float* out, int64_t n, vts_stream_t stream);

@@ -302,6 +302,43 @@ def test_feed_forward_block(M, d, F, how, mode):
         assert l2_rel(a.grad, b.grad) < 2e-5, (nm, l2_rel(a.grad, b.grad))
 
 
+@pytest.mark.parametrize("M,how", [(9000, "hash"), (1100, "keep"), (640, "eval"), (70, "hash")])
+def test_feed_forward_backward_by_recomputation(M, how):
+    """bf16x3 mode, d_model 64, dim_feedforward 2048: vts_ffn_fwd keeps only the packed relu/dropout mask and
+    vts_ffn_bwd_recompute works the hidden activations and their gradient out again inside the weight-gradient
+    kernel.  Same results as the path that stores both [tokens, 2048] tensors (the order of the fp32 sums differs)."""
+    import vts
+    from vts import functional as Fn
+    from vts import _lib
+    dev = _dev()
+    d, F, p = 64, 2048, 0.2
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, d, generator=g)
+    w1 = torch.randn(F, d, generator=g) / math.sqrt(d)
+    b1 = torch.randn(F, generator=g) * 0.3
+    w2, b2 = torch.randn(d, F, generator=g) / math.sqrt(F), torch.randn(d, generator=g) * 0.1
+    dy = torch.randn(M, d, generator=g)
+    seed = 4242 if how == "hash" else 0
+    keep = (torch.rand(M, F, generator=g) >= p).float().to(dev) if how == "keep" else None
+    vts.set_mode("bf16x3")
+    try:
+        xd = x.to(dev)
+        assert _lib.load().vts_ffn_recompute_supported(xd.data_ptr(), d, M, d, F, 1) == (1 if M >= 512 else 0)
+        res = {}
+        for recompute in (True, False):
+            Fn.FFN_RECOMPUTE = recompute
+            ins = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+            y = Fn.feed_forward(*ins, keep, p, seed)
+            y.backward(dy.to(dev))
+            res[recompute] = [y.detach()] + [t.grad for t in ins]
+    finally:
+        Fn.FFN_RECOMPUTE = True
+        vts.set_mode("f32")
+    assert torch.equal(res[True][0], res[False][0])          # the forward products are the same instructions
+    for a, b, nm in zip(res[True][1:], res[False][1:], ["x", "w1", "b1", "w2", "b2"]):
+        assert l2_rel(a, b) < 1e-5, (nm, l2_rel(a, b))
+
+
 def test_large_batch_bf16x3_matches_oracle():
     """Enough windows that the layer's products run on the split-bf16 kernels."""
     import vts

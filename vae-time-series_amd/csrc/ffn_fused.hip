@@ -78,8 +78,10 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, uint4& hi, 
 }
 
 // DROP (forward): 0 no dropout, 1 float keep mask, 2 counter hash.  BITS: forward writes / backward reads
-// the packed mask (backward without it compares the saved hidden activations with 0).
-template <bool BWD, int DROP, bool BITS>
+// the packed mask (backward without it compares the saved hidden activations with 0).  MID: the [tokens, F]
+// intermediate (forward: hidden, backward: dpre) is written to memory; without it the weight gradients come from
+// ffn_wgrad_recompute_kernel below, which works both intermediates out again from x, dy and the packed mask.
+template <bool BWD, int DROP, bool BITS, bool MID = true>
 __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
         }
       }
       if (!tok_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mid_row + c * HC + hb * 16));   // streamed: not read again by this kernel
+      if constexpr (MID)
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mid_row + c * HC + hb * 16));   // streamed: not read again by this kernel
       if constexpr (!BWD && BITS) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) nzbits |= (v[e] != 0.f ? 1u : 0u) << (4 * hb + e);
@@ -315,12 +318,235 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
   }
 }
 
-template <bool BWD, int DROP, bool BITS>
+
+// ---- weight gradients of the block without the [tokens, F] intermediates in memory -----------------------------
+//   dW2[o][u] = sum_t dy[t][o] * hidden[t][u],   dW1[u][k] = sum_t dpre[t][u] * x[t][k]
+// with hidden = bit ? (x . W1^T + b1) * scale : 0 and dpre = bit ? (dy . W2) * scale : 0 worked out again per tile
+// (bit = the packed relu/dropout mask the forward pass wrote): four products per (token tile, 64 hidden units)
+// instead of two, against 3 x 4 bytes per hidden element that no longer cross HBM.
+//
+// A workgroup (four waves, one per SIMD) owns a slab of tokens and four chunks of 64 hidden units, one per wave.
+// A wave keeps its chunk's fragments of W1 and W2 (B operands of the two recomputed products) and the sixteen +
+// sixteen accumulator tiles of its 64 x 64 blocks of dW2 and dW1 in registers for the whole slab.  Tokens come in
+// tiles of 64: x and dy are split into bf16 heads and tails once per tile and written to LDS twice - token-major
+// (A operand of the recomputed products, one ds_read_b128 per fragment) and feature-major (operands of the two
+// gradient products, which contract over tokens: 8-byte reads).  The recomputed tiles never leave registers: the
+// accumulator image of a [token][unit] product (lane (g, r): tokens 4g..4g+3, unit r) IS an MFMA operand whose
+// contraction index is the token, so hidden goes into dW2's product as the B operand and dpre into dW1's as the A
+// operand straight from the registers they were computed in.  A k-step of 32 tokens takes the two 16-token tiles
+// T0, T1 of an iteration: k-slot 8g+e is token 4g+e of T0 (e < 4) or 4g+e-4 of T1; the operand read from LDS uses
+// the same order, so the sum does not notice.  Slabs are summed by ffn_slab_reduce_kernel (fixed order).
+constexpr int RT = 64;                     // tokens per staged tile
+constexpr int RP = 144;                    // row pitch in bytes of an LDS plane row (64 bf16 + 16 B: spreads the banks)
+constexpr int R_PLANE = 64 * RP;           // one plane: 64 rows
+constexpr int R_XA = 0;                    // token-major planes: x hi, x lo, dy hi, dy lo
+constexpr int R_XT = 4 * R_PLANE;          // feature-major planes, same order
+constexpr int R_BITS = 8 * R_PLANE;        // [token 64][chunk of the group 4] mask words
+constexpr int R_STAGE = R_BITS + RT * 32;  // 75 776 B
+constexpr int R_LDS = 2 * R_STAGE;
+
+struct FfnWgradParams {
+  const float* x; long ldx;        // [M][ldx]
+  const float* dy;                 // [M][64]
+  const float* w1;                 // [F][64]
+  const float* w2t;                // [F][64] = W2 transposed
+  const float* b1;                 // [F]
+  const unsigned long long* bits;  // [rows padded to 128][F / 64]
+  float scale;
+  float* slab1;                    // [nslabs][F][64] partial dW1
+  float* slab2;                    // [nslabs][64][F] partial dW2
+  int M, F, nslabs, tiles_per_slab;
+};
+
+__global__ __launch_bounds__(256) void ffn_wgrad_recompute_kernel(const FfnWgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int slab = blockIdx.x % P.nslabs, cg = blockIdx.x / P.nslabs;   // a slab's chunk groups sit nslabs apart: one XCD when nslabs % 8 == 0
+  const int nchunks = P.F / HC;
+  const int c = cg * 4 + w;                                             // this wave's chunk
+  const int tile0 = slab * P.tiles_per_slab;
+  const int ntiles_all = (P.M + RT - 1) / RT;
+  int ntiles = ntiles_all - tile0;
+  if (ntiles > P.tiles_per_slab) ntiles = P.tiles_per_slab;
+  if (ntiles < 0) ntiles = 0;
+
+  // ---- this wave's weight fragments: B operands, lane (g, r) = unit r of block hb, k = 8g.. of k-step ks
+  uint4 w1h[4][2], w1l[4][2], w2h[4][2], w2l[4][2];
+  float b1v[4];
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+    const long unit = (long)c * HC + hb * 16 + r;
+    b1v[hb] = P.b1[unit];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* p1 = P.w1 + unit * D + ks * 32 + g * 8;
+      const float* p2 = P.w2t + unit * D + ks * 32 + g * 8;
+      split8(*reinterpret_cast<const f32x4*>(p1), *reinterpret_cast<const f32x4*>(p1 + 4), w1h[hb][ks], w1l[hb][ks]);
+      split8(*reinterpret_cast<const f32x4*>(p2), *reinterpret_cast<const f32x4*>(p2 + 4), w2h[hb][ks], w2l[hb][ks]);
+    }
+  }
+  f32x4 g2[4][4], g1[4][4];          // dW2 block [o tile j][unit block hb], dW1 block [unit block hb][k tile j]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g2[i][j] = g1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: thread = 4 tokens x 4 features of x and of dy; 128 threads also carry two mask words each
+  const int tg = tid >> 4, dg = tid & 15;
+  f32x4 vx[4], vd[4];
+  uint4 vb = uint4{0u, 0u, 0u, 0u};
+  auto fetch = [&](int tile) {
+    const long tok = (long)tile * RT + 4 * tg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = tok + i < P.M;
+      vx[i] = ok ? *reinterpret_cast<const f32x4*>(P.x + (tok + i) * P.ldx + 4 * dg) : f32x4{0.f, 0.f, 0.f, 0.f};
+      vd[i] = ok ? *reinterpret_cast<const f32x4*>(P.dy + (tok + i) * D + 4 * dg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 128) {     // token tid >> 1, words 2 (tid & 1), +1 of the group's four (the mask rows are padded to 128 tokens)
+      const long t = (long)tile * RT + (tid >> 1);
+      vb = *reinterpret_cast<const uint4*>(P.bits + t * nchunks + cg * 4 + 2 * (tid & 1));
+    }
+  };
+  auto stash_one = [&](const f32x4* v, char* pa, char* pt) {      // pa, pt: the hi plane of the pair; lo follows
+    uint2 hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      split4(v[i][0], v[i][1], v[i][2], v[i][3], hi[i], lo[i]);
+      *reinterpret_cast<uint2*>(pa + (4 * tg + i) * RP + 8 * dg) = hi[i];
+      *reinterpret_cast<uint2*>(pa + R_PLANE + (4 * tg + i) * RP + 8 * dg) = lo[i];
+    }
+    // 4 x 4 transpose of 16-bit elements: feature 4 dg + q of tokens 4 tg .. 4 tg + 3
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      auto col = [&](const uint2* m) -> uint2 {
+        const unsigned a0 = q < 2 ? m[0].x : m[0].y, a1 = q < 2 ? m[1].x : m[1].y;
+        const unsigned a2 = q < 2 ? m[2].x : m[2].y, a3 = q < 2 ? m[3].x : m[3].y;
+        if (q & 1) return uint2{(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
+        return uint2{(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
+      };
+      *reinterpret_cast<uint2*>(pt + (4 * dg + q) * RP + 8 * tg) = col(hi);
+      *reinterpret_cast<uint2*>(pt + R_PLANE + (4 * dg + q) * RP + 8 * tg) = col(lo);
+    }
+  };
+  auto stash = [&](int buf) {
+    char* st = lds + buf * R_STAGE;
+    stash_one(vx, st + R_XA, st + R_XT);
+    stash_one(vd, st + R_XA + 2 * R_PLANE, st + R_XT + 2 * R_PLANE);
+    if (tid < 128) *reinterpret_cast<uint4*>(st + R_BITS + (tid >> 1) * 32 + (tid & 1) * 16) = vb;
+  };
+
+  if (ntiles > 0) {
+    fetch(tile0);
+    stash(0);
+  }
+  __syncthreads();
+  const int bitpos = 16 * (r >> 2) + (r & 3);       // + 4 hb: this lane's unit inside a mask word
+  for (int ti = 0; ti < ntiles; ++ti) {
+    const int buf = ti & 1;
+    const char* st = lds + buf * R_STAGE;
+    if (ti + 1 < ntiles) fetch(tile0 + ti + 1);      // in flight during this tile's products
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+      // ---- the two recomputed products: [token][unit] tiles of this wave's chunk for tokens 32 it .. 32 it + 31
+      f32x4 a1[2][4], a2[2][4];
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) a1[T][hb] = a2[T][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          const char* row = st + R_XA + (32 * it + 16 * T + r) * RP + 64 * ks + 16 * g;
+          const bf16x8 xh = *reinterpret_cast<const bf16x8*>(row), xl = *reinterpret_cast<const bf16x8*>(row + R_PLANE);
+          const bf16x8 dh = *reinterpret_cast<const bf16x8*>(row + 2 * R_PLANE), dl = *reinterpret_cast<const bf16x8*>(row + 3 * R_PLANE);
+#pragma unroll
+          for (int hb = 0; hb < 4; ++hb) {
+            a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, __builtin_bit_cast(bf16x8, w1l[hb][ks]), a1[T][hb], 0, 0, 0);
+            a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, __builtin_bit_cast(bf16x8, w1h[hb][ks]), a1[T][hb], 0, 0, 0);
+            a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, __builtin_bit_cast(bf16x8, w1h[hb][ks]), a1[T][hb], 0, 0, 0);
+            a2[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, w2l[hb][ks]), a2[T][hb], 0, 0, 0);
+            a2[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, __builtin_bit_cast(bf16x8, w2h[hb][ks]), a2[T][hb], 0, 0, 0);
+            a2[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, w2h[hb][ks]), a2[T][hb], 0, 0, 0);
+          }
+        }
+      // ---- mask, bias, scale; then head / tail fragments with the token as contraction index
+      unsigned long long word[2][4];
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          word[T][e] = *reinterpret_cast<const unsigned long long*>(st + R_BITS + (32 * it + 16 * T + 4 * g + e) * 32 + w * 8);
+      uint4 hh[4], hl[4], ph[4], pl[4];
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool on = (word[T][e] >> (bitpos + 4 * hb)) & 1ull;
+            a1[T][hb][e] = on ? (a1[T][hb][e] + b1v[hb]) * P.scale : 0.f;
+            a2[T][hb][e] = on ? a2[T][hb][e] * P.scale : 0.f;
+          }
+        split8(a1[0][hb], a1[1][hb], hh[hb], hl[hb]);
+        split8(a2[0][hb], a2[1][hb], ph[hb], pl[hb]);
+      }
+      // ---- the gradient products: feature-major fragments of dy (A of dW2's) and x (B of dW1's)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const char* row = st + R_XT + (16 * j + r) * RP + 64 * it + 8 * g;
+        auto frag = [&](int plane) -> bf16x8 {
+          const uint2 lo = *reinterpret_cast<const uint2*>(row + plane * R_PLANE);
+          const uint2 hi = *reinterpret_cast<const uint2*>(row + plane * R_PLANE + 32);
+          return __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+        };
+        const bf16x8 xh = frag(0), xl = frag(1), dh = frag(2), dl = frag(3);
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+          g2[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, hl[hb]), g2[j][hb], 0, 0, 0);
+          g2[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, __builtin_bit_cast(bf16x8, hh[hb]), g2[j][hb], 0, 0, 0);
+          g2[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, hh[hb]), g2[j][hb], 0, 0, 0);
+          g1[hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ph[hb]), xl, g1[hb][j], 0, 0, 0);
+          g1[hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pl[hb]), xh, g1[hb][j], 0, 0, 0);
+          g1[hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ph[hb]), xh, g1[hb][j], 0, 0, 0);
+        }
+      }
+    }
+    if (ti + 1 < ntiles) stash(buf ^ 1);             // the other buffer: every wave left it a barrier ago
+    __syncthreads();
+  }
+  // ---- this slab's partial blocks: lane (g, r) holds rows 4g..4g+3 of column r of every 16 x 16 tile
+  float* s2 = P.slab2 + (size_t)slab * D * P.F;
+  float* s1 = P.slab1 + (size_t)slab * P.F * D;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s2[(size_t)(16 * j + 4 * g + e) * P.F + (size_t)c * HC + hb * 16 + r] = g2[j][hb][e];
+        s1[((size_t)c * HC + hb * 16 + 4 * g + e) * D + 16 * j + r] = g1[hb][j][e];
+      }
+}
+
+// out[i] = sum over slabs of part[s][i], in slab order
+__global__ void ffn_slab_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n4, int nslabs) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+    for (int k = 1; k < nslabs; ++k) s += reinterpret_cast<const f32x4*>(part)[(long)k * n4 + i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+
+template <bool BWD, int DROP, bool BITS, bool MID = true>
 int launch_b2b(const FfnParams& P, hipStream_t st) {
   static vts_lds_mask done{0};
-  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_b2b_kernel<BWD, DROP, BITS>), LDS_BYTES, &done, "ffn_b2b"))
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_b2b_kernel<BWD, DROP, BITS, MID>), LDS_BYTES, &done, "ffn_b2b"))
     return rc;
-  hipLaunchKernelGGL((ffn_b2b_kernel<BWD, DROP, BITS>), dim3((unsigned)((P.M + TOK - 1) / TOK)), dim3(512), LDS_BYTES, st, P);
+  hipLaunchKernelGGL((ffn_b2b_kernel<BWD, DROP, BITS, MID>), dim3((unsigned)((P.M + TOK - 1) / TOK)), dim3(512), LDS_BYTES, st, P);
   VTS_CHECK_LAUNCH("ffn_b2b");
   return VTS_OK;
 }
@@ -339,6 +565,12 @@ int vts_ffn_fused_fwd(const float* x, long ldx, const float* w1, const float* b1
   P.keep = keep; P.seed = seed; P.thresh = thresh; P.scale = scale;
   P.mid = hidden; P.bits_out = bits; P.out = y; P.ldo = D; P.M = M; P.F = F;
   const int drop = keep ? 1 : (thresh ? 2 : 0);
+  if (!hidden) {      // nothing but the packed mask is kept for backward (vts_ffn_bwd_recompute)
+    if (!bits) { vts_set_error("ffn_fwd: without a hidden buffer the packed mask is required"); return VTS_ERR_ARG; }
+    if (drop == 2) return launch_b2b<false, 2, true, false>(P, st);
+    if (drop == 1) return launch_b2b<false, 1, true, false>(P, st);
+    return launch_b2b<false, 0, true, false>(P, st);
+  }
   if (bits) {
     if (drop == 2) return launch_b2b<false, 2, true>(P, st);
     if (drop == 1) return launch_b2b<false, 1, true>(P, st);
@@ -361,5 +593,46 @@ int vts_ffn_fused_bwd_dx(const float* dy, const float* w1, const float* w2, floa
   P.x = dy; P.ldx = D; P.wa = w2t; P.wb = w1t;
   P.scale = scale; P.mid = dpre; P.hidden = hidden; P.bits_in = bits;
   P.out = dx; P.ldo = lddx; P.colpart = colpart; P.M = M; P.F = F;
+  if (!dpre) {
+    if (!bits) { vts_set_error("ffn_bwd: without a dpre buffer the packed mask is required"); return VTS_ERR_ARG; }
+    return launch_b2b<true, 0, true, false>(P, st);
+  }
   return bits ? launch_b2b<true, 0, true>(P, st) : launch_b2b<true, 0, false>(P, st);
+}
+
+// Weight gradients by recomputation (see ffn_wgrad_recompute_kernel).  slabs: vts_ffn_wgrad_recompute_slab_floats
+// floats of scratch; w2t: W2 transposed, [F][64] (vts_ffn_fused_bwd_dx leaves it in its scratch argument).
+int vts_ffn_wgrad_recompute_nslabs(long M, long F) {
+  const long groups = F / (4 * HC), tiles = (M + RT - 1) / RT;
+  long n = groups > 0 ? 256 / groups : 1;       // about one workgroup per compute unit
+  if (n > 64) n = 64;
+  if (n > tiles) n = tiles;
+  return (int)(n < 1 ? 1 : n);
+}
+size_t vts_ffn_wgrad_recompute_slab_floats(long M, long F) { return (size_t)2 * vts_ffn_wgrad_recompute_nslabs(M, F) * F * D; }
+bool vts_ffn_wgrad_recompute_supported(long M, long d, long F, long ldx, const void* x) {
+  return d == D && F % (4 * HC) == 0 && F >= 4 * HC && (ldx % 4) == 0 && vts_aligned16(x) && M > 0;
+}
+int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const float* w1, const float* b1, const float* w2t,
+                            const unsigned long long* bits, float scale, float* slabs, float* dw1, float* dw2, int M, int F,
+                            hipStream_t st) {
+  FfnWgradParams P{};
+  P.x = x; P.ldx = ldx; P.dy = dy; P.w1 = w1; P.w2t = w2t; P.b1 = b1; P.bits = bits; P.scale = scale;
+  P.M = M; P.F = F;
+  P.nslabs = vts_ffn_wgrad_recompute_nslabs(M, F);
+  const int tiles = (M + RT - 1) / RT;
+  P.tiles_per_slab = (tiles + P.nslabs - 1) / P.nslabs;
+  P.slab1 = slabs;
+  P.slab2 = slabs + (size_t)P.nslabs * F * D;
+  static vts_lds_mask done{0};
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_wgrad_recompute_kernel), R_LDS, &done, "ffn_wgrad_recompute"))
+    return rc;
+  hipLaunchKernelGGL(ffn_wgrad_recompute_kernel, dim3((unsigned)(P.nslabs * (F / (4 * HC)))), dim3(256), R_LDS, st, P);
+  VTS_CHECK_LAUNCH("ffn_wgrad_recompute");
+  const long n4 = (long)F * D / 4;
+  hipLaunchKernelGGL(ffn_slab_reduce_kernel, dim3(128), dim3(256), 0, st, P.slab1, dw1, n4, P.nslabs);
+  VTS_CHECK_LAUNCH("ffn_slab_reduce");
+  hipLaunchKernelGGL(ffn_slab_reduce_kernel, dim3(128), dim3(256), 0, st, P.slab2, dw2, n4, P.nslabs);
+  VTS_CHECK_LAUNCH("ffn_slab_reduce");
+  return VTS_OK;
 }

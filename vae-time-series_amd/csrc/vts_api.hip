@@ -45,6 +45,12 @@ int vts_ffn_fused_fwd(const float* x, long ldx, const float* w1, const float* b1
 int vts_ffn_fused_bwd_dx(const float* dy, const float* w1, const float* w2, float* w1t, float* w2t,
                          const float* hidden, const unsigned long long* bits, float scale, float* dpre, float* dx,
                          long lddx, float* colpart, int M, int F, hipStream_t st);
+int vts_ffn_wgrad_recompute_nslabs(long M, long F);
+size_t vts_ffn_wgrad_recompute_slab_floats(long M, long F);
+bool vts_ffn_wgrad_recompute_supported(long M, long d, long F, long ldx, const void* x);
+int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const float* w1, const float* b1, const float* w2t,
+                            const unsigned long long* bits, float scale, float* slabs, float* dw1, float* dw2, int M, int F,
+                            hipStream_t st);
 int vts_attn_mha(int bwd, const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, long ldo,
                  float* lse, const unsigned char* keep, float drop_p, unsigned long long seed, const float* dout,
                  long lddo, float* dq, long lddq, float* dk, float* dv, long lddkv, int B, int T, int Tq, int nhead,
@@ -963,7 +969,9 @@ int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, c
                 const float* keep, float drop_p, uint64_t seed, float* hidden, void* mask, float* y, int64_t M,
                 int64_t d, int64_t F, int dtype_mode, vts_stream_t stream) {
   VTS_MODE_CHECK(dtype_mode);
-  VTS_REQUIRE(x && w1 && w2 && hidden && y && M > 0 && d > 0 && F > 0 && ldx >= d, "ffn_fwd: bad arguments");
+  VTS_REQUIRE(x && w1 && w2 && y && M > 0 && d > 0 && F > 0 && ldx >= d, "ffn_fwd: bad arguments");
+  VTS_REQUIRE(hidden || (mask && b1 && b2 && vts_ffn_recompute_supported(x, ldx, M, d, F, dtype_mode)),
+              "ffn_fwd: hidden may be NULL only with a mask and where vts_ffn_recompute_supported() says so");
   VTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ffn_fwd: drop_p %g outside [0, 1)", (double)drop_p);
   VTS_REQUIRE(fits_int(M) && fits_int(d) && fits_int(F), "ffn_fwd: dimension too large");
   VTS_REQUIRE(!mask || (F % 64 == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0),
@@ -1021,6 +1029,58 @@ int vts_ffn_bwd(const float* dy, const float* x, int64_t ldx, const float* w1, c
     VTS_RC(vts_gemm_linear_dx(ws.dpre, F, w1, dx, lddx, (int)M, (int)F, (int)d, 0, nullptr, 0, nullptr, 1.f, nullptr,
                               mode1, st));
   return vts_gemm_linear_dw(ws.dpre, F, x, ldx, dw1, l1.slabs, l1.ksplit, (int)M, (int)F, (int)d, 0, mode1, st);
+}
+
+// ---- backward of the block from x, dy and the packed mask alone (no [tokens, F] tensor in memory)
+struct FfnRcWs {
+  float* w1t;        // [d][F], [F][d]: the weights transposed
+  float* w2t;
+  float* colpart1;   // [ceil(M/128)][F] column sums of dpre
+  float* colpart2;   // column-sum partials of dy
+  float* slabs;      // per-slab partial weight gradients
+  size_t total;
+};
+static FfnRcWs ffn_rc_layout(void* base, int64_t M, int64_t d, int64_t F) {
+  FfnRcWs w{};
+  char* p = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  w.w1t = reinterpret_cast<float*>(p + off); off += round256((size_t)d * F * sizeof(float));
+  w.w2t = reinterpret_cast<float*>(p + off); off += round256((size_t)d * F * sizeof(float));
+  w.colpart1 = reinterpret_cast<float*>(p + off); off += round256((size_t)((M + 127) / 128) * F * sizeof(float));
+  w.colpart2 = reinterpret_cast<float*>(p + off); off += round256((size_t)vts_ew_colsum_chunks((int)M) * d * sizeof(float));
+  w.slabs = reinterpret_cast<float*>(p + off); off += round256(vts_ffn_wgrad_recompute_slab_floats(M, F) * sizeof(float));
+  w.total = off;
+  return w;
+}
+int vts_ffn_recompute_supported(const float* x, int64_t ldx, int64_t M, int64_t d, int64_t F, int dtype_mode) {
+  if (dtype_mode != 1 || M <= 0 || d <= 0 || F <= 0 || !fits_int(M) || !fits_int(F)) return 0;
+  if (linear_mode(dtype_mode, M, d, F) != 1 || linear_mode(dtype_mode, M, F, d) != 1) return 0;
+  return (vts_ffn_fused_supported(M, d, F, ldx, x, nullptr) && vts_ffn_wgrad_recompute_supported(M, d, F, ldx, x)) ? 1 : 0;
+}
+size_t vts_ffn_bwd_recompute_workspace_bytes(int64_t M, int64_t d, int64_t F) { return ffn_rc_layout(nullptr, M, d, F).total; }
+
+int vts_ffn_bwd_recompute(const float* dy, const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2,
+                          const void* mask, float drop_scale, float* dx, int64_t lddx, float* dw1, float* db1, float* dw2,
+                          float* db2, void* workspace, size_t workspace_bytes, int64_t M, int64_t d, int64_t F,
+                          int dtype_mode, vts_stream_t stream) {
+  VTS_MODE_CHECK(dtype_mode);
+  VTS_REQUIRE(dy && x && w1 && b1 && w2 && mask && dx && dw1 && db1 && dw2 && db2 && workspace,
+              "ffn_bwd_recompute: null pointer");
+  VTS_REQUIRE(vts_ffn_recompute_supported(x, ldx, M, d, F, dtype_mode), "ffn_bwd_recompute: not planned for M %ld, d %ld, F %ld in mode %d (see vts_ffn_recompute_supported)",
+              (long)M, (long)d, (long)F, dtype_mode);
+  VTS_REQUIRE(vts_aligned16(dy) && vts_aligned16(w1) && vts_aligned16(mask) && vts_aligned16(workspace) && (lddx % 4) == 0,
+              "ffn_bwd_recompute: dy, w1, mask and the workspace must be 16-byte aligned, lddx a multiple of 4");
+  const FfnRcWs ws = ffn_rc_layout(workspace, M, d, F);
+  VTS_REQUIRE(workspace_bytes >= ws.total, "ffn_bwd_recompute: workspace %zu B < required %zu B", workspace_bytes, ws.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned long long* bits = reinterpret_cast<const unsigned long long*>(mask);
+  // dx and the column sums of dpre (db1) from one pass over the chunks; dpre itself stays on chip
+  VTS_RC(vts_ffn_fused_bwd_dx(dy, w1, w2, ws.w1t, ws.w2t, nullptr, bits, drop_scale, nullptr, dx, lddx, ws.colpart1, (int)M,
+                              (int)F, st));
+  VTS_RC(vts_colsum_partials(ws.colpart1, db1, (int)((M + 127) / 128), (int)F, F, 0, st));
+  VTS_RC(vts_ew_colsum_rows(dy, d, (int)M, (int)d, ws.colpart2, st));
+  VTS_RC(vts_colsum_partials(ws.colpart2, db2, vts_ew_colsum_chunks((int)M), (int)d, d, 0, st));
+  return vts_ffn_wgrad_recompute(x, ldx, dy, w1, b1, ws.w2t, bits, drop_scale, ws.slabs, dw1, dw2, (int)M, (int)F, st);
 }
 
 // ------------------------------------------------------------------- transformer encoder pieces

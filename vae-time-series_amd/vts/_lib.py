@@ -117,6 +117,10 @@ SIGNATURES = {
                            _int, _ptr]),
     "vts_ffn_bwd": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr,
                            _sz, _i64, _i64, _i64, _int, _ptr]),
+    "vts_ffn_recompute_supported": (_int, [_ptr, _i64, _i64, _i64, _i64, _int]),
+    "vts_ffn_bwd_recompute_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vts_ffn_bwd_recompute": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _ptr, _ptr, _ptr, _ptr,
+                                     _ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_mha_fwd": (_int, [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _u64, _i64, _i64, _i64, _i64,
                            _i64, _ptr]),
     "vts_mha_bwd": (_int, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _f32, _u64, _ptr, _i64,

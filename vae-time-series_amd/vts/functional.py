@@ -31,6 +31,9 @@ CHAIN_MAX_ROWS = 16384
 CHAIN_TAPS = None
 # test aid: when a list, feed_forward appends the hidden activations dropout(relu(linear1(x))) of every block it runs
 FFN_TAPS = None
+# the feed-forward block's backward pass from x, dy and the packed mask alone where the library offers it
+# (vts_ffn_bwd_recompute); False = keep the [tokens, dim_feedforward] activations as vts_ffn_bwd wants them
+FFN_RECOMPUTE = True
 
 
 def set_fused_chains(on: bool) -> None:
@@ -424,12 +427,18 @@ class _FeedForward(torch.autograd.Function):
         Fh = w1.shape[0]
         N = w2.shape[0]
         w1, w2, b1, b2 = w1.contiguous(), w2.contiguous(), b1.contiguous(), b2.contiguous()
-        # rows padded to the kernels' 128-token tiles; only the first M are meaningful
-        h = torch.empty(lib.vts_ffn_hidden_bytes(M, Fh) // 4, device=x.device, dtype=torch.float32)[:M * Fh].view(M, Fh)
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         mask_bytes = lib.vts_ffn_mask_bytes(M, Fh)
         mask = L.workspace(mask_bytes, x.device) if mask_bytes else None
         keep = _c(keep)
+        # Where the library can work the hidden activations out again in backward (bf16x3 mode, the fused kernels'
+        # shapes) nothing but the packed relu/dropout mask is kept: no [tokens, dim_feedforward] tensor is written.
+        recompute = bool(FFN_RECOMPUTE and mask is not None and K == N and
+                         lib.vts_ffn_recompute_supported(L.ptr(x), x.stride(0), M, K, Fh, _MODE))
+        h = None
+        if not recompute or FFN_TAPS is not None:
+            # rows padded to the kernels' 128-token tiles; only the first M are meaningful
+            h = torch.empty(lib.vts_ffn_hidden_bytes(M, Fh) // 4, device=x.device, dtype=torch.float32)[:M * Fh].view(M, Fh)
         L.check(L.timer.call(f"ffn_fwd {M}x{Fh}x{K}", lib.vts_ffn_fwd, L.ptr(x), x.stride(0), L.ptr(w1), L.ptr(b1),
                              L.ptr(w2), L.ptr(b2), L.ptr(keep), drop_p, seed, L.ptr(h),
                              None if mask is None else L.wptr(mask), L.ptr(y), M, K, Fh, _MODE, L.stream()),
@@ -437,21 +446,29 @@ class _FeedForward(torch.autograd.Function):
         if FFN_TAPS is not None:
             FFN_TAPS.append(h.detach())
         dropped = keep is not None or (bool(seed) and drop_p > 0)
-        ctx.cfg = (M, K, Fh, 1.0 / (1.0 - drop_p) if dropped else 1.0)
-        ctx.save_for_backward(x, w1, w2, h, mask)
+        ctx.cfg = (M, K, Fh, 1.0 / (1.0 - drop_p) if dropped else 1.0, recompute)
+        ctx.save_for_backward(x, w1, w2, b1 if recompute else h, mask)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.load()
         x, w1, w2, h, mask = ctx.saved_tensors
-        M, K, Fh, scale = ctx.cfg
+        M, K, Fh, scale, recompute = ctx.cfg
         dev = x.device
         dy = dy.contiguous()
-        dx = torch.empty(M, K, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dx = torch.empty(M, K, device=dev, dtype=torch.float32) if (ctx.needs_input_grad[0] or recompute) else None
         dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
         db1 = torch.empty(Fh, device=dev, dtype=torch.float32)
         db2 = torch.empty(K, device=dev, dtype=torch.float32)
+        if recompute:
+            ws_bytes = lib.vts_ffn_bwd_recompute_workspace_bytes(M, K, Fh)
+            ws = L.workspace(ws_bytes, dev)
+            L.check(L.timer.call(f"ffn_bwd {M}x{Fh}x{K}", lib.vts_ffn_bwd_recompute, L.ptr(dy), L.ptr(x), x.stride(0),
+                                 L.ptr(w1), L.ptr(h), L.ptr(w2), L.wptr(mask), scale, L.ptr(dx), K, L.ptr(dw1), L.ptr(db1),
+                                 L.ptr(dw2), L.ptr(db2), L.wptr(ws), ws_bytes, M, K, Fh, _MODE, L.stream()),
+                    "vts_ffn_bwd_recompute")
+            return dx, dw1, db1, dw2, db2, None, None, None
         ws_bytes = lib.vts_ffn_bwd_workspace_bytes(M, K, Fh)
         ws = L.workspace(ws_bytes, dev)
         L.check(L.timer.call(f"ffn_bwd {M}x{Fh}x{K}", lib.vts_ffn_bwd, L.ptr(dy), L.ptr(x), x.stride(0), L.ptr(w1),
