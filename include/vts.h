@@ -449,7 +449,9 @@ int vts_ffn_bwd(const float* dy, const float* x, int64_t ldx, const float* w1, c
  * and writes only the packed mask, and vts_ffn_bwd_recompute works hidden and the pre-activation gradient out
  * again from x, dy, the weights and that mask, tile by tile, inside the kernel that accumulates dw1 and dw2
  * (six products instead of four; 12 bytes per hidden element less HBM traffic, forward and backward together).
- * Same arguments as vts_ffn_bwd with b1 in place of hidden; dx is required.  nn.TransformerEncoderLayer's
+ * Same arguments as vts_ffn_bwd with b1 in place of hidden; dx is required; mask must be the buffer that very
+ * forward call wrote (16-byte aligned, vts_ffn_mask_bytes(M, F) bytes: behind the mask words it carries the weight
+ * image of the forward kernel, which the weight-gradient kernel reads).  nn.TransformerEncoderLayer's
  * linear1 / relu / dropout / linear2 at vae-models/mixture-vae-transformer.py:39. */
 int vts_ffn_recompute_supported(const float* x, int64_t ldx, int64_t M, int64_t d, int64_t F, int dtype_mode);
 size_t vts_ffn_bwd_recompute_workspace_bytes(int64_t M, int64_t d, int64_t F);

@@ -334,7 +334,7 @@ def test_feed_forward_backward_by_recomputation(M, how):
     finally:
         Fn.FFN_RECOMPUTE = True
         vts.set_mode("f32")
-    assert torch.equal(res[True][0], res[False][0])          # the forward products are the same instructions
+    assert l2_rel(res[True][0], res[False][0]) < 1e-6        # (the second product sums the units in another order)
     for a, b, nm in zip(res[True][1:], res[False][1:], ["x", "w1", "b1", "w2", "b2"]):
         assert l2_rel(a, b) < 1e-5, (nm, l2_rel(a, b))
 

@@ -319,6 +319,231 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 }
 
 
+// ---- the block without its [tokens, F] intermediate in memory: weights as a packed image, the chunk in registers ---
+// Used when nothing but the packed mask is kept for backward.  Per chunk of 64 hidden units the two weight slices
+// are read from a bf16 head/tail IMAGE that a small kernel writes once per call (the kernel above splits the fp32
+// weights again in every workgroup and chunk) and that arrives in LDS by DMA, no registers or VALU involved:
+//   WA [unit 64][k 64]     A operand of the first product, computed transposed: [unit][token] = WA . in^T
+//   WB [col 64][unit 64]   B operand of the second: out[token][col] += mid[token][unit] . WB^T
+//   b1 [unit 64] fp32      (forward)
+// forward: in = x, WA = W1 rows, WB = W2 rows; backward: in = dy, WA = W2^T rows, WB = W1^T rows.
+// The accumulator image of the transposed first product - lane (g, r): units 4g..4g+3 of block hb for token r - is,
+// after the epilogue and the head/tail split, an A operand of the second product as it stands: row = token r,
+// k-slots 0..3 = units 4g..4g+3 of block 2kk, 4..7 = those of block 2kk+1; the B operand is read from WB in the same
+// unit order (two 8-byte pieces).  So the intermediate never touches LDS, and a wave (32 tokens, two per SIMD)
+// runs 96 MFMAs per chunk against 16 + 32 fragment reads.  Column sums of the gradient (db1) are left to the
+// weight-gradient kernel, which recomputes the same tile anyway.
+constexpr int CP = 144;                        // row pitch of an image plane: 64 bf16 + 16 B (spreads the banks)
+constexpr int C_PLANE = 64 * CP;
+constexpr int C_WA = 0, C_WB = 2 * C_PLANE, C_B1 = 4 * C_PLANE;
+constexpr int C_IMG = 4 * C_PLANE + 1024;      // 37 KiB per chunk: WA hi, WA lo, WB hi, WB lo, b1 (+ padding)
+constexpr int C_LDS = 2 * C_IMG;
+constexpr int C_TOK = 256;                     // tokens per workgroup: eight waves x 32
+
+// image[c] for every chunk c; one thread per (chunk, WA | WB, row, pair of columns)
+__global__ void ffn_pack_image_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ b1,
+                                      char* __restrict__ image, int F, int bwd) {
+  const long total = (long)(F / HC) * 2 * 64 * 32;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cp = (int)(idx & 31), row = (int)((idx >> 5) & 63), which = (int)((idx >> 11) & 1);
+    const long c = idx >> 12;
+    float v0, v1;
+    if (which == 0) {       // WA[row = unit][col = k]
+      if (!bwd) { v0 = w1[(c * HC + row) * D + 2 * cp]; v1 = w1[(c * HC + row) * D + 2 * cp + 1]; }
+      else { v0 = w2[(long)(2 * cp) * F + c * HC + row]; v1 = w2[(long)(2 * cp + 1) * F + c * HC + row]; }
+    } else {                // WB[row = out column][col = unit]
+      if (!bwd) { v0 = w2[(long)row * F + c * HC + 2 * cp]; v1 = w2[(long)row * F + c * HC + 2 * cp + 1]; }
+      else { v0 = w1[(c * HC + 2 * cp) * D + row]; v1 = w1[(c * HC + 2 * cp + 1) * D + row]; }
+    }
+    unsigned hi, lo;
+    split2(v0, v1, hi, lo);
+    char* dst = image + c * C_IMG + (which ? C_WB : C_WA) + row * CP + cp * 4;
+    *reinterpret_cast<unsigned*>(dst) = hi;
+    *reinterpret_cast<unsigned*>(dst + C_PLANE) = lo;
+    if (which == 0 && cp == 0) reinterpret_cast<float*>(image + c * C_IMG + C_B1)[row] = b1 ? b1[c * HC + row] : 0.f;
+  }
+}
+
+struct FfnRegsParams {
+  const float* x; long ldx;        // forward: layer input; backward: dy
+  const char* image;               // [F / 64][C_IMG]
+  const float* b2;                 // forward
+  const float* keep;               // forward, DROP 1: [M][F] float 0/1
+  unsigned long long seed;
+  unsigned thresh;
+  float scale;
+  unsigned long long* bits_out;    // forward:  [rows][F / 64]
+  const unsigned long long* bits_in;   // backward
+  float* out; long ldo;            // y / dx
+  int M, F;
+};
+
+__device__ __forceinline__ unsigned ffn_lds_addr(const char* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+template <bool BWD, int DROP>
+__global__ __launch_bounds__(512) void ffn_regs_kernel(const FfnRegsParams P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * C_TOK + w * 32;
+  const int nchunks = P.F / HC;
+
+  // ---- the wave's 32 tokens as B fragments of the first product: lane (g, r) = token r of tile T, k = 8g.. of k-step ks
+  uint4 xh[2][2], xl[2][2];
+  bool ok[2];
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+    const int token = row0 + 16 * T + r;
+    ok[T] = token < P.M;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* src = P.x + (long)token * P.ldx + 32 * ks + 8 * g;
+      const f32x4 a = ok[T] ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 b = ok[T] ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      split8(a, b, xh[T][ks], xl[T][ks]);
+    }
+  }
+  // ---- chunk images: 37 one-KiB pieces, piece q by wave q % 8, straight into LDS
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(ffn_lds_addr(lds));
+  auto issue = [&](int c, int buf) {
+    const char* src = P.image + (long)c * C_IMG;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int q = w + 8 * i;
+      if (q < C_IMG / 1024) {
+        const unsigned dst = lds0 + buf * C_IMG + q * 1024;
+        const unsigned vo = lane * 16 + q * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(vo), "s"(src) : "memory", "m0");
+      }
+    }
+  };
+  issue(0, 0);
+  f32x4 acc2[2][4];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc2[T][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned long long* bits_row[2] = {nullptr, nullptr};
+  unsigned long long word_next[2] = {0ull, 0ull};
+  if constexpr (BWD) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      bits_row[T] = P.bits_in + (long)(row0 + 16 * T + r) * nchunks;
+      word_next[T] = ok[T] ? bits_row[T][0] : 0ull;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const char* img = lds + (c & 1) * C_IMG;
+    if (c + 1 < nchunks) issue(c + 1, (c & 1) ^ 1);      // the other buffer: every wave left it a barrier ago
+    unsigned long long word[2] = {word_next[0], word_next[1]};
+    if constexpr (BWD) {
+      const int cn = c + 1 < nchunks ? c + 1 : c;
+#pragma unroll
+      for (int T = 0; T < 2; ++T) word_next[T] = ok[T] ? bits_row[T][cn] : 0ull;
+    }
+    // ---- first product, transposed: [unit 64][token 16] per tile
+    f32x4 a1[2][4];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) a1[T][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+        const char* pa = img + C_WA + (16 * hb + r) * CP + 64 * ks + 16 * g;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa), al = *reinterpret_cast<const bf16x8*>(pa + C_PLANE);
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, xl[T][ks]), a1[T][hb], 0, 0, 0);
+          a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, xh[T][ks]), a1[T][hb], 0, 0, 0);
+          a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, xh[T][ks]), a1[T][hb], 0, 0, 0);
+        }
+      }
+    // ---- epilogue in registers: lane (g, r) holds units 16 hb + 4g .. + 3 of chunk c for token r of tile T
+    uint4 sh[2][2], sl[2][2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      const long token = row0 + 16 * T + r;
+      unsigned nz = 0;
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+        f32x4 v = a1[T][hb];
+        if constexpr (!BWD) {
+          v += *reinterpret_cast<const f32x4*>(img + C_B1 + (16 * hb + 4 * g) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          const long idx = token * P.F + (long)c * HC + 16 * hb + 4 * g;
+          if constexpr (DROP == 1) {
+            if (ok[T]) v = v * *reinterpret_cast<const f32x4*>(P.keep + idx) * P.scale;
+          } else if constexpr (DROP == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = vts_hash32(P.seed, (unsigned long long)idx + e) >= P.thresh ? v[e] * P.scale : 0.f;
+          }
+          if (!ok[T]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) nz |= (v[e] != 0.f ? 1u : 0u) << (4 * hb + e);
+        } else {
+          const unsigned nib = (unsigned)(word[T] >> (16 * g + 4 * hb)) & 15u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] * P.scale : 0.f;
+        }
+        a1[T][hb] = v;
+      }
+      split8(a1[T][0], a1[T][1], sh[T][0], sl[T][0]);
+      split8(a1[T][2], a1[T][3], sh[T][1], sl[T][1]);
+      if constexpr (!BWD) {
+        // mask word of (token, chunk): 16-bit field g holds this lane's bits (bit 4 hb + e <-> unit 16 hb + 4 g + e);
+        // the four lanes of a token sit 16 lanes apart
+        const unsigned partner = __shfl_xor(nz, 16);
+        const unsigned pair = (g & 1) ? (partner | (nz << 16)) : (nz | (partner << 16));
+        const unsigned other = __shfl_xor(pair, 32);
+        const unsigned long long full = (g & 2) ? (((unsigned long long)pair << 32) | other) : (((unsigned long long)other << 32) | pair);
+        if (g == 0 && ok[T]) P.bits_out[token * nchunks + c] = full;
+      }
+    }
+    // ---- second product: out[token][col] += mid[token][unit] . WB[col][unit]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) {
+        const char* pb = img + C_WB + (16 * ob + r) * CP + 64 * kk + 8 * g;
+        auto frag = [&](const char* q) -> bf16x8 {
+          const uint2 lo = *reinterpret_cast<const uint2*>(q), hi = *reinterpret_cast<const uint2*>(q + 32);
+          return __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+        };
+        const bf16x8 bh = frag(pb), bl = frag(pb + C_PLANE);
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          acc2[T][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sh[T][kk]), bl, acc2[T][ob], 0, 0, 0);
+          acc2[T][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sl[T][kk]), bh, acc2[T][ob], 0, 0, 0);
+          acc2[T][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sh[T][kk]), bh, acc2[T][ob], 0, 0, 0);
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the next image have landed
+    __syncthreads();                                    // ... and everybody's; everybody is done with this one
+  }
+  // ---- out tile: acc2[T][ob] = C[token 16 T + 4g + reg][col 16 ob + r]
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const int col = ob * 16 + r;
+      const float bias = (!BWD && P.b2) ? P.b2[col] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = row0 + 16 * T + 4 * g + reg;
+        if (row < P.M) P.out[(long)row * P.ldo + col] = acc2[T][ob][reg] + bias;
+      }
+    }
+}
+
 // ---- weight gradients of the block without the [tokens, F] intermediates in memory -----------------------------
 //   dW2[o][u] = sum_t dy[t][o] * hidden[t][u],   dW1[u][k] = sum_t dpre[t][u] * x[t][k]
 // with hidden = bit ? (x . W1^T + b1) * scale : 0 and dpre = bit ? (dy . W2) * scale : 0 worked out again per tile
@@ -348,13 +573,13 @@ constexpr int R_LDS = 2 * R_STAGE;
 struct FfnWgradParams {
   const float* x; long ldx;        // [M][ldx]
   const float* dy;                 // [M][64]
-  const float* w1;                 // [F][64]
-  const float* w2t;                // [F][64] = W2 transposed
-  const float* b1;                 // [F]
+  const char* image_fwd;           // packed images of the forward and the backward chain kernels: their WA planes
+  const char* image_bwd;           // are W1's and W2^T's rows of a chunk as bf16 heads / tails, b1 sits in the forward one
   const unsigned long long* bits;  // [rows padded to 128][F / 64]
   float scale;
   float* slab1;                    // [nslabs][F][64] partial dW1
   float* slab2;                    // [nslabs][64][F] partial dW2
+  float* colpart;                  // [nslabs][F] partial column sums of dpre (db1)
   int M, F, nslabs, tiles_per_slab;
 };
 
@@ -375,16 +600,21 @@ __global__ __launch_bounds__(256) void ffn_wgrad_recompute_kernel(const FfnWgrad
   // ---- this wave's weight fragments: B operands, lane (g, r) = unit r of block hb, k = 8g.. of k-step ks
   uint4 w1h[4][2], w1l[4][2], w2h[4][2], w2l[4][2];
   float b1v[4];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of dpre over this lane's tokens, per unit block
+  {
+    const char* i1 = P.image_fwd + (long)c * C_IMG;
+    const char* i2 = P.image_bwd + (long)c * C_IMG;
 #pragma unroll
-  for (int hb = 0; hb < 4; ++hb) {
-    const long unit = (long)c * HC + hb * 16 + r;
-    b1v[hb] = P.b1[unit];
+    for (int hb = 0; hb < 4; ++hb) {
+      b1v[hb] = reinterpret_cast<const float*>(i1 + C_B1)[hb * 16 + r];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const float* p1 = P.w1 + unit * D + ks * 32 + g * 8;
-      const float* p2 = P.w2t + unit * D + ks * 32 + g * 8;
-      split8(*reinterpret_cast<const f32x4*>(p1), *reinterpret_cast<const f32x4*>(p1 + 4), w1h[hb][ks], w1l[hb][ks]);
-      split8(*reinterpret_cast<const f32x4*>(p2), *reinterpret_cast<const f32x4*>(p2 + 4), w2h[hb][ks], w2l[hb][ks]);
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = C_WA + (16 * hb + r) * CP + 64 * ks + 16 * g;
+        w1h[hb][ks] = *reinterpret_cast<const uint4*>(i1 + off);
+        w1l[hb][ks] = *reinterpret_cast<const uint4*>(i1 + off + C_PLANE);
+        w2h[hb][ks] = *reinterpret_cast<const uint4*>(i2 + off);
+        w2l[hb][ks] = *reinterpret_cast<const uint4*>(i2 + off + C_PLANE);
+      }
     }
   }
   f32x4 g2[4][4], g1[4][4];          // dW2 block [o tile j][unit block hb], dW1 block [unit block hb][k tile j]
@@ -490,6 +720,7 @@ __global__ __launch_bounds__(256) void ffn_wgrad_recompute_kernel(const FfnWgrad
             const bool on = (word[T][e] >> (bitpos + 4 * hb)) & 1ull;
             a1[T][hb][e] = on ? (a1[T][hb][e] + b1v[hb]) * P.scale : 0.f;
             a2[T][hb][e] = on ? a2[T][hb][e] * P.scale : 0.f;
+            cs[hb] += a2[T][hb][e];
           }
         split8(a1[0][hb], a1[1][hb], hh[hb], hl[hb]);
         split8(a2[0][hb], a2[1][hb], ph[hb], pl[hb]);
@@ -530,6 +761,14 @@ __global__ __launch_bounds__(256) void ffn_wgrad_recompute_kernel(const FfnWgrad
         s2[(size_t)(16 * j + 4 * g + e) * P.F + (size_t)c * HC + hb * 16 + r] = g2[j][hb][e];
         s1[((size_t)c * HC + hb * 16 + 4 * g + e) * D + 16 * j + r] = g1[hb][j][e];
       }
+  // column sums: the four lane groups of a unit hold disjoint tokens
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+    float v = cs[hb];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (g == 0) P.colpart[(size_t)slab * P.F + (size_t)c * HC + hb * 16 + r] = v;
+  }
 }
 
 // out[i] = sum over slabs of part[s][i], in slab order
@@ -601,7 +840,8 @@ int vts_ffn_fused_bwd_dx(const float* dy, const float* w1, const float* w2, floa
 }
 
 // Weight gradients by recomputation (see ffn_wgrad_recompute_kernel).  slabs: vts_ffn_wgrad_recompute_slab_floats
-// floats of scratch; w2t: W2 transposed, [F][64] (vts_ffn_fused_bwd_dx leaves it in its scratch argument).
+// floats of scratch; colpart: [vts_ffn_wgrad_recompute_nslabs][F] floats, partial column sums of dpre; the images are
+// those of vts_ffn_regs_fwd / vts_ffn_regs_bwd_dx.
 int vts_ffn_wgrad_recompute_nslabs(long M, long F) {
   const long groups = F / (4 * HC), tiles = (M + RT - 1) / RT;
   long n = groups > 0 ? 256 / groups : 1;       // about one workgroup per compute unit
@@ -613,11 +853,12 @@ size_t vts_ffn_wgrad_recompute_slab_floats(long M, long F) { return (size_t)2 * 
 bool vts_ffn_wgrad_recompute_supported(long M, long d, long F, long ldx, const void* x) {
   return d == D && F % (4 * HC) == 0 && F >= 4 * HC && (ldx % 4) == 0 && vts_aligned16(x) && M > 0;
 }
-int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const float* w1, const float* b1, const float* w2t,
-                            const unsigned long long* bits, float scale, float* slabs, float* dw1, float* dw2, int M, int F,
-                            hipStream_t st) {
+int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const void* image_fwd, const void* image_bwd,
+                            const unsigned long long* bits, float scale, float* slabs, float* colpart, float* dw1, float* dw2,
+                            int M, int F, hipStream_t st) {
   FfnWgradParams P{};
-  P.x = x; P.ldx = ldx; P.dy = dy; P.w1 = w1; P.w2t = w2t; P.b1 = b1; P.bits = bits; P.scale = scale;
+  P.x = x; P.ldx = ldx; P.dy = dy; P.bits = bits; P.scale = scale; P.colpart = colpart;
+  P.image_fwd = reinterpret_cast<const char*>(image_fwd); P.image_bwd = reinterpret_cast<const char*>(image_bwd);
   P.M = M; P.F = F;
   P.nslabs = vts_ffn_wgrad_recompute_nslabs(M, F);
   const int tiles = (M + RT - 1) / RT;
@@ -635,4 +876,44 @@ int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const flo
   hipLaunchKernelGGL(ffn_slab_reduce_kernel, dim3(128), dim3(256), 0, st, P.slab2, dw2, n4, P.nslabs);
   VTS_CHECK_LAUNCH("ffn_slab_reduce");
   return VTS_OK;
+}
+
+// The block through the register-chain kernel (ffn_regs_kernel).  image: vts_ffn_image_bytes(F) of scratch that the
+// call fills (forward: kept by the caller for the weight-gradient kernel).
+size_t vts_ffn_image_bytes(long F) { return (size_t)(F / HC) * C_IMG; }
+template <bool BWD, int DROP>
+static int launch_regs(const FfnRegsParams& P, hipStream_t st) {
+  static vts_lds_mask done{0};
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_regs_kernel<BWD, DROP>), C_LDS, &done, "ffn_regs")) return rc;
+  hipLaunchKernelGGL((ffn_regs_kernel<BWD, DROP>), dim3((unsigned)((P.M + C_TOK - 1) / C_TOK)), dim3(512), C_LDS, st, P);
+  VTS_CHECK_LAUNCH("ffn_regs");
+  return VTS_OK;
+}
+static int pack_image(const float* w1, const float* w2, const float* b1, void* image, int F, int bwd, hipStream_t st) {
+  hipLaunchKernelGGL(ffn_pack_image_kernel, dim3((unsigned)((F / HC) * 16)), dim3(256), 0, st, w1, w2, b1, reinterpret_cast<char*>(image), F, bwd);
+  VTS_CHECK_LAUNCH("ffn_pack_image");
+  return VTS_OK;
+}
+int vts_ffn_pack_fwd_image(const float* w1, const float* b1, const float* w2, void* image, int F, hipStream_t st) {
+  return pack_image(w1, w2, b1, image, F, 0, st);
+}
+int vts_ffn_regs_fwd(const float* x, long ldx, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* keep, unsigned long long seed, unsigned thresh, float scale, unsigned long long* bits,
+                     void* image, float* y, int M, int F, hipStream_t st) {
+  if (int rc = pack_image(w1, w2, b1, image, F, 0, st)) return rc;
+  FfnRegsParams P{};
+  P.x = x; P.ldx = ldx; P.image = reinterpret_cast<const char*>(image); P.b2 = b2; P.keep = keep; P.seed = seed;
+  P.thresh = thresh; P.scale = scale; P.bits_out = bits; P.out = y; P.ldo = D; P.M = M; P.F = F;
+  const int drop = keep ? 1 : (thresh ? 2 : 0);
+  if (drop == 2) return launch_regs<false, 2>(P, st);
+  if (drop == 1) return launch_regs<false, 1>(P, st);
+  return launch_regs<false, 0>(P, st);
+}
+int vts_ffn_regs_bwd_dx(const float* dy, const float* w1, const float* w2, const unsigned long long* bits, float scale,
+                        void* image, float* dx, long lddx, int M, int F, hipStream_t st) {
+  if (int rc = pack_image(w1, w2, nullptr, image, F, 1, st)) return rc;
+  FfnRegsParams P{};
+  P.x = dy; P.ldx = D; P.image = reinterpret_cast<const char*>(image); P.scale = scale; P.bits_in = bits;
+  P.out = dx; P.ldo = lddx; P.M = M; P.F = F;
+  return launch_regs<true, 0>(P, st);
 }

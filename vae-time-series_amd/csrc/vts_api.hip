@@ -48,9 +48,16 @@ int vts_ffn_fused_bwd_dx(const float* dy, const float* w1, const float* w2, floa
 int vts_ffn_wgrad_recompute_nslabs(long M, long F);
 size_t vts_ffn_wgrad_recompute_slab_floats(long M, long F);
 bool vts_ffn_wgrad_recompute_supported(long M, long d, long F, long ldx, const void* x);
-int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const float* w1, const float* b1, const float* w2t,
-                            const unsigned long long* bits, float scale, float* slabs, float* dw1, float* dw2, int M, int F,
-                            hipStream_t st);
+int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const void* image_fwd, const void* image_bwd,
+                            const unsigned long long* bits, float scale, float* slabs, float* colpart, float* dw1, float* dw2,
+                            int M, int F, hipStream_t st);
+size_t vts_ffn_image_bytes(long F);
+int vts_ffn_pack_fwd_image(const float* w1, const float* b1, const float* w2, void* image, int F, hipStream_t st);
+int vts_ffn_regs_fwd(const float* x, long ldx, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* keep, unsigned long long seed, unsigned thresh, float scale, unsigned long long* bits,
+                     void* image, float* y, int M, int F, hipStream_t st);
+int vts_ffn_regs_bwd_dx(const float* dy, const float* w1, const float* w2, const unsigned long long* bits, float scale,
+                        void* image, float* dx, long lddx, int M, int F, hipStream_t st);
 int vts_attn_mha(int bwd, const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, long ldo,
                  float* lse, const unsigned char* keep, float drop_p, unsigned long long seed, const float* dout,
                  long lddo, float* dq, long lddq, float* dk, float* dv, long lddkv, int B, int T, int Tq, int nhead,
@@ -962,7 +969,11 @@ static FfnWs ffn_ws_layout(void* base, int64_t M, int64_t d, int64_t F) {
 }
 
 size_t vts_ffn_hidden_bytes(int64_t M, int64_t F) { return (size_t)ffn_rows(M) * F * sizeof(float); }
-size_t vts_ffn_mask_bytes(int64_t M, int64_t F) { return (F % 64 == 0) ? (size_t)ffn_rows(M) * (F / 64) * 8 : 0; }
+// [mask words, rows padded][the forward chain kernel's weight image: kept for the recomputing backward pass]
+static size_t ffn_mask_words_bytes(int64_t M, int64_t F) { return round256((size_t)ffn_rows(M) * (F / 64) * 8); }
+size_t vts_ffn_mask_bytes(int64_t M, int64_t F) {
+  return (F % 64 == 0) ? ffn_mask_words_bytes(M, F) + round256(vts_ffn_image_bytes((long)F)) : 0;
+}
 size_t vts_ffn_bwd_workspace_bytes(int64_t M, int64_t d, int64_t F) { return ffn_ws_layout(nullptr, M, d, F).total; }
 
 int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,
@@ -970,8 +981,9 @@ int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, c
                 int64_t d, int64_t F, int dtype_mode, vts_stream_t stream) {
   VTS_MODE_CHECK(dtype_mode);
   VTS_REQUIRE(x && w1 && w2 && y && M > 0 && d > 0 && F > 0 && ldx >= d, "ffn_fwd: bad arguments");
-  VTS_REQUIRE(hidden || (mask && b1 && b2 && vts_ffn_recompute_supported(x, ldx, M, d, F, dtype_mode)),
-              "ffn_fwd: hidden may be NULL only with a mask and where vts_ffn_recompute_supported() says so");
+  VTS_REQUIRE(hidden || (mask && b1 && b2 && vts_aligned16(mask) && (!keep || vts_aligned16(keep)) &&
+                         vts_ffn_recompute_supported(x, ldx, M, d, F, dtype_mode)),
+              "ffn_fwd: hidden may be NULL only with a 16-byte aligned mask (and keep) and where vts_ffn_recompute_supported() says so");
   VTS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ffn_fwd: drop_p %g outside [0, 1)", (double)drop_p);
   VTS_REQUIRE(fits_int(M) && fits_int(d) && fits_int(F), "ffn_fwd: dimension too large");
   VTS_REQUIRE(!mask || (F % 64 == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0),
@@ -979,6 +991,13 @@ int vts_ffn_fwd(const float* x, int64_t ldx, const float* w1, const float* b1, c
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool hashed = !keep && drop_p > 0.f && seed != 0;
   const bool dropped = keep || hashed;
+  if (!hidden)       // nothing but the mask is kept: the chunk stays in registers (vts_ffn_bwd_recompute is the way back)
+    return vts_ffn_regs_fwd(x, ldx, w1, b1, w2, b2, keep, seed, hashed ? vts_drop_thresh(drop_p) : 0u,
+                            dropped ? 1.f / (1.f - drop_p) : 1.f, reinterpret_cast<unsigned long long*>(mask),
+                            reinterpret_cast<char*>(mask) + ffn_mask_words_bytes(M, F), y, (int)M, (int)F, st);
+  // (a caller that keeps hidden may still go back through vts_ffn_bwd_recompute: leave the image behind the mask words)
+  if (mask && b1 && b2 && vts_aligned16(mask) && vts_ffn_recompute_supported(x, ldx, M, d, F, dtype_mode))
+    VTS_RC(vts_ffn_pack_fwd_image(w1, b1, w2, reinterpret_cast<char*>(mask) + ffn_mask_words_bytes(M, F), (int)F, st));
   if (linear_mode(dtype_mode, M, F, d) == 1 && b1 && b2 && vts_ffn_fused_supported(M, d, F, ldx, x, keep))
     return vts_ffn_fused_fwd(x, ldx, w1, b1, w2, b2, keep, seed, hashed ? vts_drop_thresh(drop_p) : 0u,
                              dropped ? 1.f / (1.f - drop_p) : 1.f, hidden, reinterpret_cast<unsigned long long*>(mask),
@@ -1033,9 +1052,8 @@ int vts_ffn_bwd(const float* dy, const float* x, int64_t ldx, const float* w1, c
 
 // ---- backward of the block from x, dy and the packed mask alone (no [tokens, F] tensor in memory)
 struct FfnRcWs {
-  float* w1t;        // [d][F], [F][d]: the weights transposed
-  float* w2t;
-  float* colpart1;   // [ceil(M/128)][F] column sums of dpre
+  char* image;       // the backward chain kernel's weight image
+  float* colpart1;   // [slabs][F] column sums of dpre
   float* colpart2;   // column-sum partials of dy
   float* slabs;      // per-slab partial weight gradients
   size_t total;
@@ -1044,9 +1062,8 @@ static FfnRcWs ffn_rc_layout(void* base, int64_t M, int64_t d, int64_t F) {
   FfnRcWs w{};
   char* p = reinterpret_cast<char*>(base);
   size_t off = 0;
-  w.w1t = reinterpret_cast<float*>(p + off); off += round256((size_t)d * F * sizeof(float));
-  w.w2t = reinterpret_cast<float*>(p + off); off += round256((size_t)d * F * sizeof(float));
-  w.colpart1 = reinterpret_cast<float*>(p + off); off += round256((size_t)((M + 127) / 128) * F * sizeof(float));
+  w.image = p + off; off += round256(vts_ffn_image_bytes((long)F));
+  w.colpart1 = reinterpret_cast<float*>(p + off); off += round256((size_t)vts_ffn_wgrad_recompute_nslabs(M, F) * F * sizeof(float));
   w.colpart2 = reinterpret_cast<float*>(p + off); off += round256((size_t)vts_ew_colsum_chunks((int)M) * d * sizeof(float));
   w.slabs = reinterpret_cast<float*>(p + off); off += round256(vts_ffn_wgrad_recompute_slab_floats(M, F) * sizeof(float));
   w.total = off;
@@ -1066,6 +1083,7 @@ int vts_ffn_bwd_recompute(const float* dy, const float* x, int64_t ldx, const fl
   VTS_MODE_CHECK(dtype_mode);
   VTS_REQUIRE(dy && x && w1 && b1 && w2 && mask && dx && dw1 && db1 && dw2 && db2 && workspace,
               "ffn_bwd_recompute: null pointer");
+  (void)b1;   // (its values travel in the forward image behind the mask words)
   VTS_REQUIRE(vts_ffn_recompute_supported(x, ldx, M, d, F, dtype_mode), "ffn_bwd_recompute: not planned for M %ld, d %ld, F %ld in mode %d (see vts_ffn_recompute_supported)",
               (long)M, (long)d, (long)F, dtype_mode);
   VTS_REQUIRE(vts_aligned16(dy) && vts_aligned16(w1) && vts_aligned16(mask) && vts_aligned16(workspace) && (lddx % 4) == 0,
@@ -1074,13 +1092,14 @@ int vts_ffn_bwd_recompute(const float* dy, const float* x, int64_t ldx, const fl
   VTS_REQUIRE(workspace_bytes >= ws.total, "ffn_bwd_recompute: workspace %zu B < required %zu B", workspace_bytes, ws.total);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned long long* bits = reinterpret_cast<const unsigned long long*>(mask);
-  // dx and the column sums of dpre (db1) from one pass over the chunks; dpre itself stays on chip
-  VTS_RC(vts_ffn_fused_bwd_dx(dy, w1, w2, ws.w1t, ws.w2t, nullptr, bits, drop_scale, nullptr, dx, lddx, ws.colpart1, (int)M,
-                              (int)F, st));
-  VTS_RC(vts_colsum_partials(ws.colpart1, db1, (int)((M + 127) / 128), (int)F, F, 0, st));
+  const char* image_fwd = reinterpret_cast<const char*>(mask) + ffn_mask_words_bytes(M, F);   // left there by vts_ffn_fwd
+  // dx from one pass over the chunks, dpre in registers; then both weight gradients and db1 from the recomputed tiles
+  VTS_RC(vts_ffn_regs_bwd_dx(dy, w1, w2, bits, drop_scale, ws.image, dx, lddx, (int)M, (int)F, st));
   VTS_RC(vts_ew_colsum_rows(dy, d, (int)M, (int)d, ws.colpart2, st));
   VTS_RC(vts_colsum_partials(ws.colpart2, db2, vts_ew_colsum_chunks((int)M), (int)d, d, 0, st));
-  return vts_ffn_wgrad_recompute(x, ldx, dy, w1, b1, ws.w2t, bits, drop_scale, ws.slabs, dw1, dw2, (int)M, (int)F, st);
+  VTS_RC(vts_ffn_wgrad_recompute(x, ldx, dy, image_fwd, ws.image, bits, drop_scale, ws.slabs, ws.colpart1, dw1, dw2, (int)M,
+                                 (int)F, st));
+  return vts_colsum_partials(ws.colpart1, db1, vts_ffn_wgrad_recompute_nslabs(M, F), (int)F, F, 0, st);
 }
 
 // ------------------------------------------------------------------- transformer encoder pieces
