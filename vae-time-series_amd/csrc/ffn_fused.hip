@@ -550,9 +550,11 @@ __global__ __launch_bounds__(512) void ffn_regs_kernel(const FfnRegsParams P) {
 // (bit = the packed relu/dropout mask the forward pass wrote): four products per (token tile, 64 hidden units)
 // instead of two, against 3 x 4 bytes per hidden element that no longer cross HBM.
 //
-// A workgroup (four waves, one per SIMD) owns a slab of tokens and four chunks of 64 hidden units, one per wave.
-// A wave keeps its chunk's fragments of W1 and W2 (B operands of the two recomputed products) and the sixteen +
-// sixteen accumulator tiles of its 64 x 64 blocks of dW2 and dW1 in registers for the whole slab.  Tokens come in
+// A workgroup (eight waves, two per SIMD: one's mask / split arithmetic runs under the other's MFMAs) owns a slab of
+// tokens and four chunks of 64 hidden units; two waves share a chunk, one recomputes hidden and accumulates dW2,
+// the other recomputes dpre and accumulates dW1 (as its transpose, which makes the two waves' code the same up to
+// which planes and which image they read).  A wave keeps its matrix's fragments (B operand of its recomputed
+// product) and the sixteen accumulator tiles of its 64 x 64 gradient block in registers for the whole slab.  Tokens come in
 // tiles of 64: x and dy are split into bf16 heads and tails once per tile and written to LDS twice - token-major
 // (A operand of the recomputed products, one ds_read_b128 per fragment) and feature-major (operands of the two
 // gradient products, which contract over tokens: 8-byte reads).  The recomputed tiles never leave registers: the
@@ -562,7 +564,9 @@ __global__ __launch_bounds__(512) void ffn_regs_kernel(const FfnRegsParams P) {
 // T0, T1 of an iteration: k-slot 8g+e is token 4g+e of T0 (e < 4) or 4g+e-4 of T1; the operand read from LDS uses
 // the same order, so the sum does not notice.  Slabs are summed by ffn_slab_reduce_kernel (fixed order).
 constexpr int RT = 64;                     // tokens per staged tile
-constexpr int RP = 144;                    // row pitch in bytes of an LDS plane row (64 bf16 + 16 B: spreads the banks)
+constexpr int RP = 144;                    // row pitch in bytes of a token-major plane row (64 bf16 + 16 B: spreads the banks)
+constexpr int RPT = 136;                   // ... of a feature-major one (8-byte accesses only; 144 would put the staging
+                                           // writes of rows four apart on the same banks, four deep)
 constexpr int R_PLANE = 64 * RP;           // one plane: 64 rows
 constexpr int R_XA = 0;                    // token-major planes: x hi, x lo, dy hi, dy lo
 constexpr int R_XT = 4 * R_PLANE;          // feature-major planes, same order
@@ -583,68 +587,72 @@ struct FfnWgradParams {
   int M, F, nslabs, tiles_per_slab;
 };
 
-__global__ __launch_bounds__(256) void ffn_wgrad_recompute_kernel(const FfnWgradParams P) {
+__global__ __launch_bounds__(512) void ffn_wgrad_recompute_kernel(const FfnWgradParams P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int slab = blockIdx.x % P.nslabs, cg = blockIdx.x / P.nslabs;   // a slab's chunk groups sit nslabs apart: one XCD when nslabs % 8 == 0
   const int nchunks = P.F / HC;
-  const int c = cg * 4 + w;                                             // this wave's chunk
+  const int c = cg * 4 + (w >> 1);                                      // this wave's chunk ...
+  const int path = w & 1;                                               // ... and its half of the work (see above)
   const int tile0 = slab * P.tiles_per_slab;
   const int ntiles_all = (P.M + RT - 1) / RT;
   int ntiles = ntiles_all - tile0;
   if (ntiles > P.tiles_per_slab) ntiles = P.tiles_per_slab;
   if (ntiles < 0) ntiles = 0;
+  // planes of the staged tile this wave reads: token-major operand of the recomputed product, feature-major operand
+  // of the gradient product (the other tensor)
+  const int pl_rec = path ? 2 * R_PLANE : 0, pl_grad = path ? 0 : 2 * R_PLANE;
 
   // ---- this wave's weight fragments: B operands, lane (g, r) = unit r of block hb, k = 8g.. of k-step ks
-  uint4 w1h[4][2], w1l[4][2], w2h[4][2], w2l[4][2];
-  float b1v[4];
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of dpre over this lane's tokens, per unit block
+  uint4 wh[4][2], wl[4][2];
+  float bias[4];
   {
-    const char* i1 = P.image_fwd + (long)c * C_IMG;
-    const char* i2 = P.image_bwd + (long)c * C_IMG;
+    const char* img = (path ? P.image_bwd : P.image_fwd) + (long)c * C_IMG;
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
-      b1v[hb] = reinterpret_cast<const float*>(i1 + C_B1)[hb * 16 + r];
+      bias[hb] = path ? 0.f : reinterpret_cast<const float*>(img + C_B1)[hb * 16 + r];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = C_WA + (16 * hb + r) * CP + 64 * ks + 16 * g;
-        w1h[hb][ks] = *reinterpret_cast<const uint4*>(i1 + off);
-        w1l[hb][ks] = *reinterpret_cast<const uint4*>(i1 + off + C_PLANE);
-        w2h[hb][ks] = *reinterpret_cast<const uint4*>(i2 + off);
-        w2l[hb][ks] = *reinterpret_cast<const uint4*>(i2 + off + C_PLANE);
+        wh[hb][ks] = *reinterpret_cast<const uint4*>(img + off);
+        wl[hb][ks] = *reinterpret_cast<const uint4*>(img + off + C_PLANE);
       }
     }
   }
-  f32x4 g2[4][4], g1[4][4];          // dW2 block [o tile j][unit block hb], dW1 block [unit block hb][k tile j]
+  f32x4 G[4][4];                     // gradient block [feature tile j][unit block hb]: dW2[o][unit] or dW1[unit][k] transposed
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of the recomputed tile over this lane's tokens, per unit block
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) g2[i][j] = g1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int hb = 0; hb < 4; ++hb) G[j][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging: thread = 4 tokens x 4 features of x and of dy; 128 threads also carry two mask words each
-  const int tg = tid >> 4, dg = tid & 15;
-  f32x4 vx[4], vd[4];
+  // ---- staging: thread = 4 tokens x 4 features of x (threads 0..255) or of dy; 128 threads also carry two mask words each
+  const int tg = (tid >> 4) & 15, dg = tid & 15;
+  const bool is_dy = tid >= 256;
+  const float* sbase = is_dy ? P.dy : P.x;
+  const long sld = is_dy ? D : P.ldx;
+  f32x4 vx[4];
   uint4 vb = uint4{0u, 0u, 0u, 0u};
   auto fetch = [&](int tile) {
     const long tok = (long)tile * RT + 4 * tg;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = tok + i < P.M;
-      vx[i] = ok ? *reinterpret_cast<const f32x4*>(P.x + (tok + i) * P.ldx + 4 * dg) : f32x4{0.f, 0.f, 0.f, 0.f};
-      vd[i] = ok ? *reinterpret_cast<const f32x4*>(P.dy + (tok + i) * D + 4 * dg) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < 4; ++i)
+      vx[i] = tok + i < P.M ? *reinterpret_cast<const f32x4*>(sbase + (tok + i) * sld + 4 * dg) : f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 128) {     // token tid >> 1, words 2 (tid & 1), +1 of the group's four (the mask rows are padded to 128 tokens)
       const long t = (long)tile * RT + (tid >> 1);
       vb = *reinterpret_cast<const uint4*>(P.bits + t * nchunks + cg * 4 + 2 * (tid & 1));
     }
   };
-  auto stash_one = [&](const f32x4* v, char* pa, char* pt) {      // pa, pt: the hi plane of the pair; lo follows
+  auto stash = [&](int buf) {
+    char* st = lds + buf * R_STAGE;
+    char* pa = st + R_XA + (is_dy ? 2 * R_PLANE : 0);      // the hi plane of the pair; lo follows
+    char* pt = st + R_XT + (is_dy ? 2 * R_PLANE : 0);
     uint2 hi[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      split4(v[i][0], v[i][1], v[i][2], v[i][3], hi[i], lo[i]);
+      split4(vx[i][0], vx[i][1], vx[i][2], vx[i][3], hi[i], lo[i]);
       *reinterpret_cast<uint2*>(pa + (4 * tg + i) * RP + 8 * dg) = hi[i];
       *reinterpret_cast<uint2*>(pa + R_PLANE + (4 * tg + i) * RP + 8 * dg) = lo[i];
     }
@@ -657,14 +665,9 @@ __global__ __launch_bounds__(256) void ffn_wgrad_recompute_kernel(const FfnWgrad
         if (q & 1) return uint2{(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
         return uint2{(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
       };
-      *reinterpret_cast<uint2*>(pt + (4 * dg + q) * RP + 8 * tg) = col(hi);
-      *reinterpret_cast<uint2*>(pt + R_PLANE + (4 * dg + q) * RP + 8 * tg) = col(lo);
+      *reinterpret_cast<uint2*>(pt + (4 * dg + q) * RPT + 8 * tg) = col(hi);
+      *reinterpret_cast<uint2*>(pt + R_PLANE + (4 * dg + q) * RPT + 8 * tg) = col(lo);
     }
-  };
-  auto stash = [&](int buf) {
-    char* st = lds + buf * R_STAGE;
-    stash_one(vx, st + R_XA, st + R_XT);
-    stash_one(vd, st + R_XA + 2 * R_PLANE, st + R_XT + 2 * R_PLANE);
     if (tid < 128) *reinterpret_cast<uint4*>(st + R_BITS + (tid >> 1) * 32 + (tid & 1) * 16) = vb;
   };
 
@@ -680,94 +683,100 @@ __global__ __launch_bounds__(256) void ffn_wgrad_recompute_kernel(const FfnWgrad
     if (ti + 1 < ntiles) fetch(tile0 + ti + 1);      // in flight during this tile's products
 #pragma unroll 1
     for (int it = 0; it < 2; ++it) {
-      // ---- the two recomputed products: [token][unit] tiles of this wave's chunk for tokens 32 it .. 32 it + 31
-      f32x4 a1[2][4], a2[2][4];
+      // ---- the recomputed product: [token][unit] tiles of this wave's chunk for tokens 32 it .. 32 it + 31
+      f32x4 a[2][4];
 #pragma unroll
       for (int T = 0; T < 2; ++T)
 #pragma unroll
-        for (int hb = 0; hb < 4; ++hb) a1[T][hb] = a2[T][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int hb = 0; hb < 4; ++hb) a[T][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
-          const char* row = st + R_XA + (32 * it + 16 * T + r) * RP + 64 * ks + 16 * g;
+          const char* row = st + R_XA + pl_rec + (32 * it + 16 * T + r) * RP + 64 * ks + 16 * g;
           const bf16x8 xh = *reinterpret_cast<const bf16x8*>(row), xl = *reinterpret_cast<const bf16x8*>(row + R_PLANE);
-          const bf16x8 dh = *reinterpret_cast<const bf16x8*>(row + 2 * R_PLANE), dl = *reinterpret_cast<const bf16x8*>(row + 3 * R_PLANE);
 #pragma unroll
-          for (int hb = 0; hb < 4; ++hb) {
-            a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, __builtin_bit_cast(bf16x8, w1l[hb][ks]), a1[T][hb], 0, 0, 0);
-            a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, __builtin_bit_cast(bf16x8, w1h[hb][ks]), a1[T][hb], 0, 0, 0);
-            a1[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, __builtin_bit_cast(bf16x8, w1h[hb][ks]), a1[T][hb], 0, 0, 0);
-            a2[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, w2l[hb][ks]), a2[T][hb], 0, 0, 0);
-            a2[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, __builtin_bit_cast(bf16x8, w2h[hb][ks]), a2[T][hb], 0, 0, 0);
-            a2[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, w2h[hb][ks]), a2[T][hb], 0, 0, 0);
-          }
+          for (int hb = 0; hb < 4; ++hb)
+            a[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, __builtin_bit_cast(bf16x8, wl[hb][ks]), a[T][hb], 0, 0, 0);
+#pragma unroll
+          for (int hb = 0; hb < 4; ++hb)
+            a[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, __builtin_bit_cast(bf16x8, wh[hb][ks]), a[T][hb], 0, 0, 0);
+#pragma unroll
+          for (int hb = 0; hb < 4; ++hb)
+            a[T][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, __builtin_bit_cast(bf16x8, wh[hb][ks]), a[T][hb], 0, 0, 0);
         }
-      // ---- mask, bias, scale; then head / tail fragments with the token as contraction index
-      unsigned long long word[2][4];
+      // ---- mask and bias (the dropout scale is applied to the finished sums); then head / tail fragments with the
+      // token as contraction index
+      unsigned wlo[2][4];      // this lane's units of token (T, e): bit 4 hb
 #pragma unroll
       for (int T = 0; T < 2; ++T)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          word[T][e] = *reinterpret_cast<const unsigned long long*>(st + R_BITS + (32 * it + 16 * T + 4 * g + e) * 32 + w * 8);
-      uint4 hh[4], hl[4], ph[4], pl[4];
+          wlo[T][e] = (unsigned)(*reinterpret_cast<const unsigned long long*>(st + R_BITS + (32 * it + 16 * T + 4 * g + e) * 32 + (w >> 1) * 8) >> bitpos);
+      uint4 fh[4], fl[4];
 #pragma unroll
       for (int hb = 0; hb < 4; ++hb) {
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool on = (word[T][e] >> (bitpos + 4 * hb)) & 1ull;
-            a1[T][hb][e] = on ? (a1[T][hb][e] + b1v[hb]) * P.scale : 0.f;
-            a2[T][hb][e] = on ? a2[T][hb][e] * P.scale : 0.f;
-            cs[hb] += a2[T][hb][e];
+            a[T][hb][e] = (wlo[T][e] >> (4 * hb)) & 1u ? a[T][hb][e] + bias[hb] : 0.f;
+            cs[hb] += a[T][hb][e];
           }
-        split8(a1[0][hb], a1[1][hb], hh[hb], hl[hb]);
-        split8(a2[0][hb], a2[1][hb], ph[hb], pl[hb]);
+        split8(a[0][hb], a[1][hb], fh[hb], fl[hb]);
       }
-      // ---- the gradient products: feature-major fragments of dy (A of dW2's) and x (B of dW1's)
+      // ---- the gradient product: feature-major fragments of the other tensor as A, the recomputed tile as B
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const char* row = st + R_XT + (16 * j + r) * RP + 64 * it + 8 * g;
+        const char* row = st + R_XT + pl_grad + (16 * j + r) * RPT + 64 * it + 8 * g;
         auto frag = [&](int plane) -> bf16x8 {
           const uint2 lo = *reinterpret_cast<const uint2*>(row + plane * R_PLANE);
           const uint2 hi = *reinterpret_cast<const uint2*>(row + plane * R_PLANE + 32);
           return __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
         };
-        const bf16x8 xh = frag(0), xl = frag(1), dh = frag(2), dl = frag(3);
+        const bf16x8 th = frag(0), tl = frag(1);
 #pragma unroll
-        for (int hb = 0; hb < 4; ++hb) {
-          g2[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, hl[hb]), g2[j][hb], 0, 0, 0);
-          g2[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, __builtin_bit_cast(bf16x8, hh[hb]), g2[j][hb], 0, 0, 0);
-          g2[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, __builtin_bit_cast(bf16x8, hh[hb]), g2[j][hb], 0, 0, 0);
-          g1[hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ph[hb]), xl, g1[hb][j], 0, 0, 0);
-          g1[hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pl[hb]), xh, g1[hb][j], 0, 0, 0);
-          g1[hb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ph[hb]), xh, g1[hb][j], 0, 0, 0);
-        }
+        for (int hb = 0; hb < 4; ++hb)
+          G[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th, __builtin_bit_cast(bf16x8, fl[hb]), G[j][hb], 0, 0, 0);
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb)
+          G[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl, __builtin_bit_cast(bf16x8, fh[hb]), G[j][hb], 0, 0, 0);
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb)
+          G[j][hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th, __builtin_bit_cast(bf16x8, fh[hb]), G[j][hb], 0, 0, 0);
       }
     }
     if (ti + 1 < ntiles) stash(buf ^ 1);             // the other buffer: every wave left it a barrier ago
     __syncthreads();
   }
-  // ---- this slab's partial blocks: lane (g, r) holds rows 4g..4g+3 of column r of every 16 x 16 tile
-  float* s2 = P.slab2 + (size_t)slab * D * P.F;
-  float* s1 = P.slab1 + (size_t)slab * P.F * D;
+  // ---- this slab's partial blocks: lane (g, r) holds features 16 j + 4g .. + 3 of unit 16 hb + r
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int hb = 0; hb < 4; ++hb)
+    for (int hb = 0; hb < 4; ++hb) G[j][hb] *= P.scale;
+  if (path == 0) {
+    float* s2 = P.slab2 + (size_t)slab * D * P.F;            // dW2[o][unit]
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s2[(size_t)(16 * j + 4 * g + e) * P.F + (size_t)c * HC + hb * 16 + r] = g2[j][hb][e];
-        s1[((size_t)c * HC + hb * 16 + 4 * g + e) * D + 16 * j + r] = g1[hb][j][e];
-      }
-  // column sums: the four lane groups of a unit hold disjoint tokens
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-  for (int hb = 0; hb < 4; ++hb) {
-    float v = cs[hb];
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (g == 0) P.colpart[(size_t)slab * P.F + (size_t)c * HC + hb * 16 + r] = v;
+      for (int hb = 0; hb < 4; ++hb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s2[(size_t)(16 * j + 4 * g + e) * P.F + (size_t)c * HC + hb * 16 + r] = G[j][hb][e];
+  } else {
+    float* s1 = P.slab1 + (size_t)slab * P.F * D;            // dW1[unit][k]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb)
+        *reinterpret_cast<f32x4*>(s1 + ((size_t)c * HC + hb * 16 + r) * D + 16 * j + 4 * g) = G[j][hb];
+    // column sums of dpre: the four lane groups of a unit hold disjoint tokens
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      float v = cs[hb];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (g == 0) P.colpart[(size_t)slab * P.F + (size_t)c * HC + hb * 16 + r] = v * P.scale;
+    }
   }
 }
 
@@ -868,7 +877,7 @@ int vts_ffn_wgrad_recompute(const float* x, long ldx, const float* dy, const voi
   static vts_lds_mask done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(ffn_wgrad_recompute_kernel), R_LDS, &done, "ffn_wgrad_recompute"))
     return rc;
-  hipLaunchKernelGGL(ffn_wgrad_recompute_kernel, dim3((unsigned)(P.nslabs * (F / (4 * HC)))), dim3(256), R_LDS, st, P);
+  hipLaunchKernelGGL(ffn_wgrad_recompute_kernel, dim3((unsigned)(P.nslabs * (F / (4 * HC)))), dim3(512), R_LDS, st, P);
   VTS_CHECK_LAUNCH("ffn_wgrad_recompute");
   const long n4 = (long)F * D / 4;
   hipLaunchKernelGGL(ffn_slab_reduce_kernel, dim3(128), dim3(256), 0, st, P.slab1, dw1, n4, P.nslabs);
