@@ -782,7 +782,7 @@ def main():
         roofline["floors_ms"] = {"mfma": round(floor_mfma_ms, 4), "hbm": round(floor_hbm_ms, 4)}
         # HBM bytes per launch of the dominant kernel: measured by this invocation (--traffic), else null with the
         # path of the committed measurement of the same command
-        roofline["traffic_profile"] = "profiles/r02_pmc_hbm_traffic.json"
+        roofline["traffic_profile"] = "profiles/r03_pmc_hbm_traffic.json"
         if traffic is not None:
             roofline["traffic_measured"] = traffic
             sub = TRAFFIC_KERNELS.get(dom)

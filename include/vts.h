@@ -205,6 +205,13 @@ int vts_lstm_wgrad_planes(const void* dg_planes, const void* x_planes, int x_is_
                           float* dw_hh, int accumulate, void* workspace, size_t workspace_bytes, int64_t B, int64_t T,
                           int64_t Cin, int64_t H, int dtype_mode, vts_stream_t stream);
 
+/* ---- Test hooks and development switches (vts_debug_*) -------------------------------------------------------
+ * NOT part of the product interface: the only process-wide mutable state of the library, exported so that the
+ * test suite can reach the time-out paths of the kernels whose workgroups wait for each other and can run the
+ * alternative kernels of one shape against each other.  Every one of them has a default that a production caller
+ * never needs to touch (the defaults are what the measurements in the documentation were taken with); none changes
+ * results beyond the order of fp32 sums, except the *_fault hooks, which make a launch fail on purpose.  Changing
+ * one while launches of other host threads are being enqueued affects those launches too. */
 /* Test hook, process-wide: member `member` (0..7) of every cluster of the bench-sized forward recurrence withholds
  * its hand-off flags and the waits are cut short, so the timeout path above can be exercised; -1 = off (default). */
 void vts_debug_set_cluster_fault(int member);
@@ -234,6 +241,7 @@ void vts_debug_set_fused_fwd(int on);
 /* Test hook, process-wide: member `member` (0 or 1) of every such pair withholds what it owes its peer and the
  * waits are cut short, so the timeout path (vts_lstm_recurrent_bwd_status) can be exercised; -1 = off (default). */
 void vts_debug_set_pair_fault(int member);
+/* ---- end of the test hooks ---- */
 
 /* row-major [B,T,N] <-> tile16 [Bp*T,N]; to_rows = 0 packs (padding rows zeroed), 1 unpacks. */
 int vts_tile16_convert(float* rows, float* tiled, int64_t B, int64_t T, int64_t N, int to_rows,

@@ -37,9 +37,9 @@ constexpr int WB_THREADS = 256;
 constexpr int WB_VEC = 4;          // float4 pieces per thread
 constexpr int WB_SPAN = WB_THREADS * WB_VEC * 4;   // floats of one window handled by a workgroup
 
-// grid (B, ceil(T*C / WB_SPAN)).  Dynamic LDS: C ColStat entries when standardising.
+// grid (windows side by side, ceil(T*C / WB_SPAN)).  Dynamic LDS: C ColStat entries when standardising.
 __global__ __launch_bounds__(WB_THREADS) void windows_x_kernel(const float* __restrict__ series, long Nt, int C,
-                                                                const long long* __restrict__ starts, int T,
+                                                                const long long* __restrict__ starts, long B, int T,
                                                                 const double* __restrict__ mean,
                                                                 const double* __restrict__ scale,
                                                                 float* __restrict__ X) {
@@ -53,19 +53,22 @@ __global__ __launch_bounds__(WB_THREADS) void windows_x_kernel(const float* __re
     }
     __syncthreads();
   }
-  const long b = blockIdx.x;
   const long TC = (long)T * C;
+  const float qnan = __builtin_nanf("");
+  const bool vec_ok = (TC & 3) == 0;                     // every window then starts on a 16-byte boundary
+  const bool pair_ok = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(series) & 7) == 0;
+  // T*C < 2^31 (checked by the caller): 32-bit offsets; the channel of the thread's first element is
+  // found once and then stepped, so the loops carry no division
+  const unsigned o0 = blockIdx.y * (unsigned)WB_SPAN + threadIdx.x * 4u;
+  const unsigned cfirst = std_on ? o0 % (unsigned)C : 0u;
+  const unsigned cstep = (unsigned)(WB_THREADS * 4) % (unsigned)C;
+  // a workgroup walks over windows blockIdx.x, + gridDim.x, ...: the column table above is built once for all of them
+  for (long b = blockIdx.x; b < B; b += gridDim.x) {
   const long start = starts[b];
   const bool inside = start >= 0 && start + T <= Nt;     // a window that leaves the series reads as NaN
   const float* src = series + start * C;
   float* dst = X + b * TC;
-  const bool vec_ok = (TC & 3) == 0;                     // every window then starts on a 16-byte boundary
-  const float qnan = __builtin_nanf("");
-  // T*C < 2^31 (checked by the caller): 32-bit offsets; the channel of the thread's first element is
-  // found once and then stepped, so the loop carries no division
-  const unsigned o0 = blockIdx.y * (unsigned)WB_SPAN + threadIdx.x * 4u;
-  unsigned c0 = std_on ? o0 % (unsigned)C : 0u;
-  const unsigned cstep = (unsigned)(WB_THREADS * 4) % (unsigned)C;
+  unsigned c0 = cfirst;
 #pragma unroll
   for (int it = 0; it < WB_VEC; ++it) {
     const long o = (long)o0 + (long)it * (WB_THREADS * 4);
@@ -74,6 +77,11 @@ __global__ __launch_bounds__(WB_THREADS) void windows_x_kernel(const float* __re
     float v[4];
     if (!inside) {
       v[0] = v[1] = v[2] = v[3] = qnan;
+    } else if (n == 4 && pair_ok) {
+      // an even channel count puts every window start on an 8-byte boundary: two aligned 8-byte loads (a 16-byte
+      // load that straddles its natural boundary is served at a lower rate)
+      const float2 x0 = *reinterpret_cast<const float2*>(src + o), x1 = *reinterpret_cast<const float2*>(src + o + 2);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x1.x; v[3] = x1.y;
     } else if (n == 4) {
       const f32x4_u x = *reinterpret_cast<const f32x4_u*>(src + o);   // rows of C floats: 4-byte alignment only
       v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
@@ -95,6 +103,7 @@ __global__ __launch_bounds__(WB_THREADS) void windows_x_kernel(const float* __re
     } else {
       for (int j = 0; j < n; ++j) dst[o + j] = v[j];
     }
+  }
   }
 }
 
@@ -200,11 +209,15 @@ int vts_windows_build(const float* series, int64_t Nt, int64_t C, const int64_t*
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (X) {
     const long TC = (long)T * C;
-    const dim3 grid((unsigned)B, (unsigned)vts_cdiv(TC, WB_SPAN));
-    VTS_REQUIRE(grid.y <= 65535u, "windows_build: window of %ld floats is too long", TC);
+    const unsigned gy = (unsigned)vts_cdiv(TC, WB_SPAN);
+    VTS_REQUIRE(gy <= 65535u, "windows_build: window of %ld floats is too long", TC);
+    // about eight workgroups per compute unit; each builds its column table once and then walks over windows
+    long gx = 2048 / gy;
+    gx = gx < 1 ? 1 : (gx > B ? B : gx);
+    const dim3 grid((unsigned)gx, gy);
     const size_t lds = x_mean ? (size_t)C * sizeof(ColStat) : 0;
     hipLaunchKernelGGL(windows_x_kernel, grid, dim3(WB_THREADS), lds, st, series, (long)Nt, (int)C,
-                       reinterpret_cast<const long long*>(starts), (int)T, x_mean, x_scale, X);
+                       reinterpret_cast<const long long*>(starts), (long)B, (int)T, x_mean, x_scale, X);
     VTS_CHECK_LAUNCH("windows_x");
   }
   if (y) {
