@@ -482,6 +482,14 @@ int vts_dropout_mask(uint64_t seed, float drop_p, uint8_t* keep, int64_t n, vts_
 int vts_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   int64_t step, float lr, float beta1, float beta2, float eps, float grad_scale,
                   vts_stream_t stream);
+/* vts_adam_step behind a guard: n_guard (1..64) int32 words of device memory, e.g. the status words of the step's
+ * recurrent launches (vts_lstm_recurrent_{fwd,bwd}_status, vts_lstm_fused_fwd_status).  If any of them is non-zero
+ * when the kernel runs, no buffer is touched: gradients of a launch that timed out never reach the parameters, and
+ * the host can enqueue the update without first waiting for the step to finish.  No counterpart in the reference
+ * (torch raises on the host). */
+int vts_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                          float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* guard,
+                          int64_t n_guard, vts_stream_t stream);
 
 /* ---- three-component latent mixture (Gaussian / GPD / Bernoulli) ----
  * graph/vae_mixture_graph_model.py with use_gcn = use_d_knn = False, use_gpd = use_bernoulli = True, the

@@ -3,8 +3,9 @@ wait for each other) when they do not have the GPU to themselves, and how a miss
 
 * another kernel holds compute units while they are launched (tests/helpers/occupy.hip, the stand-in for a
   collective's kernel on a side stream): results must equal the undisturbed run's and every status word must be 0;
-* a peer that never delivers (the library's test hook): train_step and DataParallelTrainer raise
-  vts.RecurrenceTimeout before the optimizer update instead of stepping on NaN gradients;
+* a peer that never delivers (the library's test hook): the optimizer update of that step is skipped on the device
+  (vts_adam_step_guarded reads the step's status words) and train_step / DataParallelTrainer raise
+  vts.RecurrenceTimeout once the words have reached the host, instead of stepping on NaN gradients;
 * vts_lstm_recurrent_bwd_status after launches of the kernels that wait for nobody: 0, whatever the workspace held;
 * the data-parallel exact loss with a real mixture model, its statistics reduced through an RCCL group.
 The LSTM itself is the reference's nn.LSTM call (vae-models/mixture-vae-DE.py:45,60)."""
@@ -94,6 +95,9 @@ def test_recurrences_beside_a_kernel_that_holds_compute_units(bf16x3, held_cus):
 
 
 def test_train_step_raises_on_a_missed_handoff(bf16x3):
+    """A launch that timed out: the optimizer update of that step is skipped ON THE DEVICE (its status words guard
+    vts_adam_step_guarded), and vts.RecurrenceTimeout, naming the kernel, is raised once the words have reached the
+    host - by vts.raise_on_recurrence_timeout() (synchronous) or at the start of a later step."""
     import vts
     from vts import _lib
     lib = _lib.load()
@@ -105,25 +109,42 @@ def test_train_step_raises_on_a_missed_handoff(bf16x3):
     opt = vts.Adam(vts.FlatParameters(model), lr=1e-3)
     x, y = torch.randn(B, T, Cin, device=dev), torch.randn(B, 1, device=dev)
     vts.train_step(model, opt, x, y)
+    vts.raise_on_recurrence_timeout()            # clean
     before = opt.flat.data.clone()
+    moments = opt.exp_avg.clone()
     for hook, kernel in ((lib.vts_debug_set_pair_fault, "lstm_rec3p_bwd_kernel"),
                          (lib.vts_debug_set_cluster_fault, "lstm_rec3c_fwd_kernel")):
         hook(1)
         try:
-            with pytest.raises(vts.RecurrenceTimeout, match=kernel):
-                vts.train_step(model, opt, x, y)
+            vts.train_step(model, opt, x, y)                 # does not raise: nothing has been read back yet
         finally:
             hook(-1)
-        torch.cuda.synchronize()
+        with pytest.raises(vts.RecurrenceTimeout, match=kernel):
+            vts.raise_on_recurrence_timeout()
         assert torch.equal(opt.flat.data, before), "no update may be made from a launch that timed out"
-    trainer = vts.DataParallelTrainer(model, lr=1e-3)        # (no process group: the single-rank path of the trainer)
-    lib.vts_debug_set_pair_fault(0)
+        assert torch.equal(opt.exp_avg, moments), "... nor to the optimizer's moments"
+    # the asynchronous route: the next step that finds the words on the host raises before it launches anything
+    lib.vts_debug_set_pair_fault(1)
     try:
-        with pytest.raises(vts.RecurrenceTimeout, match="lstm_rec3p_bwd_kernel"):
-            trainer.step(x, y)
+        vts.train_step(model, opt, x, y)
     finally:
         lib.vts_debug_set_pair_fault(-1)
+    torch.cuda.synchronize()
+    with pytest.raises(vts.RecurrenceTimeout, match="lstm_rec3p_bwd_kernel"):
+        vts.train_step(model, opt, x, y)
+    assert torch.equal(opt.flat.data, before)
+    trainer = vts.DataParallelTrainer(model, lr=1e-3)        # (no process group: the single-rank path of the trainer)
+    tbefore = trainer.flat.data.clone()
+    lib.vts_debug_set_pair_fault(0)
+    try:
+        trainer.step(x, y)
+    finally:
+        lib.vts_debug_set_pair_fault(-1)
+    with pytest.raises(vts.RecurrenceTimeout, match="lstm_rec3p_bwd_kernel"):
+        vts.raise_on_recurrence_timeout()
+    assert torch.equal(trainer.flat.data, tbefore)
     loss = vts.train_step(model, opt, x, y)      # the next step is clean
+    vts.raise_on_recurrence_timeout()
     assert torch.isfinite(loss).item() and not torch.equal(opt.flat.data, before)
     # switched off, the step goes through (and poisons the parameters: the caller's choice)
     vts.set_status_checks(False)

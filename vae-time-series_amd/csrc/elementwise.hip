@@ -700,6 +700,28 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// The same update behind a guard: n_guard words of device memory (status words of this step's launches; at most 64);
+// if any of them is non-zero the kernel returns without touching a buffer.  The decision is made on the device, so
+// the host need not wait for the step to finish before it enqueues the update.
+__global__ void adam_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1,
+                                    float bc2_sqrt, float gscale, const int* __restrict__ guard, int n_guard) {
+  int any = 0;
+  for (int k = 0; k < n_guard; ++k) any |= guard[k];
+  if (any != 0) return;
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 // Step counter on the device, for callers that replay a recorded launch sequence (HIP graphs): one thread
 // advances the counter and leaves this step's bias corrections beside it; the update kernel reads them.
 // state: [int64 step][float 1 - b1^t][float sqrt(1 - b2^t)]
@@ -1119,6 +1141,14 @@ int vts_ew_adam(float* p, const float* g, float* m, float* v, long n, float lr, 
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1,
                      bc2_sqrt, gscale);
   VTS_CHECK_LAUNCH("adam");
+  return VTS_OK;
+}
+
+int vts_ew_adam_guarded(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        float bc1, float bc2_sqrt, float gscale, const int* guard, int n_guard, hipStream_t st) {
+  hipLaunchKernelGGL(adam_guarded_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1,
+                     bc2_sqrt, gscale, guard, n_guard);
+  VTS_CHECK_LAUNCH("adam_guarded");
   return VTS_OK;
 }
 

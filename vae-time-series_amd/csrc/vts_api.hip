@@ -10,6 +10,8 @@
 // ---- internal entry points (gemm_f32.hip, lstm_rec_f32.hip, elementwise.hip) -------------------
 int vts_ew_adam_counted(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                         long long* state, float gscale, hipStream_t st);
+int vts_ew_adam_guarded(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        float bc1, float bc2_sqrt, float gscale, const int* guard, int n_guard, hipStream_t st);
 int vts_ew_elbo_sums(int kind, const float* recon, const float* y, const float* mean, const float* logvar,
                      const float* scale, const float* shape, const float* klpart, int nkl, float thr, long B, int fs,
                      int L, float* part, float* sums, hipStream_t st);
@@ -1166,6 +1168,18 @@ int vts_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   return vts_ew_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
                      grad_scale, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vts_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                          float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* guard,
+                          int64_t n_guard, vts_stream_t stream) {
+  VTS_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step_guarded: bad arguments");
+  VTS_REQUIRE(guard && n_guard >= 1 && n_guard <= 64 && (reinterpret_cast<uintptr_t>(guard) & 3u) == 0,
+              "adam_step_guarded: 1 to 64 guard words, 4-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  return vts_ew_adam_guarded(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2),
+                             grad_scale, reinterpret_cast<const int*>(guard), (int)n_guard, reinterpret_cast<hipStream_t>(stream));
 }
 
 int vts_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -129,6 +129,7 @@ SIGNATURES = {
     "vts_dropout_bwd": (_int, [_ptr, _ptr, _f32, _u64, _ptr, _i64, _ptr]),
     "vts_dropout_mask": (_int, [_u64, _f32, _ptr, _i64, _ptr]),
     "vts_adam_step": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr]),
+    "vts_adam_step_guarded": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _i64, _ptr]),
     "vts_adam_step_counted": (_int, [_ptr, _ptr, _ptr, _ptr, _i64, _ptr, _f32, _f32, _f32, _f32, _f32, _ptr]),
     "vts_gather_chunks": (_int, [_ptr, _ptr, _ptr, _i64, _ptr, _ptr]),
     "vts_scale": (_int, [_ptr, _ptr, _ptr, _i64, _ptr]),

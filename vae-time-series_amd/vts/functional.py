@@ -77,13 +77,16 @@ class RecurrenceTimeout(RuntimeError):
 class _RecurrenceStatus:
     """Status words of the recurrent launches of the current step.
 
-    The cluster forward kernel and the pair backward kernel (bf16x3, hidden 256) are grids of workgroups that wait
-    for each other with bounded polls.  A workgroup that never hears from its peer writes NaN and sets its launch's
-    status word (vts_lstm_recurrent_{fwd,bwd}_status).  torch's own LSTM would raise on the host; here every launch
-    that can time out copies its word into a small device array (stream-ordered, four bytes), and
-    ``raise_on_timeout`` - called by train_step and DataParallelTrainer before the optimizer update - reads the
-    array back and raises RecurrenceTimeout naming the kernel, so that NaN gradients never reach the parameters.
-    Reading back is one host synchronisation per step, made only in steps that ran such a kernel."""
+    The cluster forward kernel, the pair backward kernel and the fused forward kernel (bf16x3, hidden 256) are grids
+    of workgroups that wait for each other with bounded polls.  A workgroup that never hears from its peer writes NaN
+    and sets its launch's status word (vts_lstm_recurrent_{fwd,bwd}_status, vts_lstm_fused_fwd_status).  torch's own
+    LSTM would raise on the host; here every launch that can time out copies its word into a small device array
+    (stream-ordered, four bytes).  At the end of a step ``finish_step`` hands that array to the optimizer as the
+    GUARD of its update kernel (vts_adam_step_guarded: any non-zero word and the parameters stay as they are - under
+    data parallelism after a MAX all-reduce of the words, so that every rank decides alike) and starts an
+    asynchronous copy of it to the host; the copy is looked at when it has arrived - at the start of a later step, or
+    in ``raise_on_timeout`` - and a non-zero word raises RecurrenceTimeout naming the kernel.  No host
+    synchronisation is made on the way, and NaN gradients never reach the parameters."""
 
     SLOTS = 64
 
@@ -91,6 +94,7 @@ class _RecurrenceStatus:
         self.enabled = True
         self.words = {}     # device index -> int32[SLOTS]
         self.names = {}     # device index -> names of the launches noted since the last read
+        self.pending = []   # (event, pinned host copy of a finished step's words, names, reduced over ranks?)
 
     def note(self, name: str, query, ws, ws_bytes: int, B: int, T: int, H: int) -> None:
         if not self.enabled or H != 256 or _MODE != 1 or torch.cuda.is_current_stream_capturing():
@@ -107,9 +111,59 @@ class _RecurrenceStatus:
         names.append(name)
 
     def begin_step(self) -> None:
-        """Forget launches that nobody asked about (a step that ended in an exception, forward-only calls)."""
+        """Look at the status words of earlier steps that have reached the host by now (raises RecurrenceTimeout if
+        one is set) and forget launches that nobody asked about (a step that ended in an exception, forward-only
+        calls)."""
+        self.poll(block=False)
         for dev in self.names:
             self.names[dev] = []
+
+    def finish_step(self, device=None, reduce=None):
+        """The status words of this step's launches on ``device`` as the guard of the optimizer update: an int32
+        device tensor (one word per launch), or None if no launch of the step can time out.  ``reduce`` (data
+        parallelism) is applied to the tensor in place first, e.g. a MAX all-reduce.  Also queues the words'
+        asynchronous copy to the host for ``poll``."""
+        if not self.enabled or not any(self.names.values()) or torch.cuda.is_current_stream_capturing():
+            return None
+        for dev, names in self.names.items():
+            if not names or (device is not None and torch.device(device).index not in (None, dev)):
+                continue
+            words = self.words[dev][:len(names)]
+            if reduce is not None:
+                reduce(words)
+            host = torch.empty(len(names), dtype=torch.int32, pin_memory=True)
+            host.copy_(words, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending.append((ev, host, list(names), reduce is not None))
+            self.names[dev] = []
+            return words
+        return None
+
+    def poll(self, block: bool) -> None:
+        """Raise RecurrenceTimeout if a finished step's words (those that have arrived; all of them if ``block``)
+        hold a non-zero one."""
+        keep, bad, reduced = [], [], False
+        for ev, host, names, red in self.pending:
+            if block:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, host, names, red))
+                continue
+            hit = [(n, v) for n, v in zip(names, host.tolist()) if v != 0]
+            bad += hit
+            reduced = reduced or (red and bool(hit))
+        self.pending = keep
+        if bad:
+            raise RecurrenceTimeout(self._message(bad, reduced))
+
+    @staticmethod
+    def _message(bad, reduced=False) -> str:
+        return ("a workgroup of " + ", ".join(f"{n} (status {v:#x})" for n, v in bad) + " gave up waiting for its peer "
+                "(another kernel held compute units for longer than the poll bound, about a second)"
+                + (" on this rank or another one" if reduced else "") + ": the launch's outputs are NaN and the "
+                "optimizer update of that step was not made.  VTS_LSTM_CLUSTER=0 / VTS_LSTM_PAIR_BWD=0 select the "
+                "one-workgroup kernels, which wait for nobody.")
 
     def read(self, device=None):
         """[(launch name, status word)] of the launches noted since the last read (synchronises with the device)."""
@@ -122,15 +176,15 @@ class _RecurrenceStatus:
         return out
 
     def raise_on_timeout(self) -> None:
-        if not self.enabled or not any(self.names.values()) or torch.cuda.is_current_stream_capturing():
+        """The synchronous check: waits for every finished step's words and for the current step's launches."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self.poll(block=True)
+        if not self.enabled or not any(self.names.values()):
             return
         bad = [(n, v) for n, v in self.read() if v != 0]
         if bad:
-            raise RecurrenceTimeout(
-                "a workgroup of " + ", ".join(f"{n} (status {v:#x})" for n, v in bad) + " gave up waiting for its peer "
-                "(another kernel held compute units for longer than the poll bound, about a second): the launch's "
-                "outputs are NaN and no optimizer update was made.  VTS_LSTM_CLUSTER=0 / VTS_LSTM_PAIR_BWD=0 select "
-                "the one-workgroup kernels, which wait for nobody.")
+            raise RecurrenceTimeout(self._message(bad))
 
 
 recurrence_status = _RecurrenceStatus()

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .train import Adam, FlatParameters, forward_loss, raise_on_recurrence_timeout
+from .train import Adam, FlatParameters, forward_loss
 
 
 def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -132,8 +132,17 @@ class DataParallelTrainer:
         else:
             self.flat.gather_grads()
         if apply_update:
-            raise_on_recurrence_timeout()       # (a rank that raises here leaves the others waiting in their next collective)
-            self.opt.step(grad_scale=1.0 / self.world)
+            # every rank must make the same decision about the update: the status words are MAX-reduced first, so a
+            # launch that timed out on one rank (whose NaN gradients the all-reduce above has spread) stops them all,
+            # and all of them raise RecurrenceTimeout from a later step
+            reduce = None
+            if self.distributed:
+                reduce = lambda words: dist.all_reduce(words, op=dist.ReduceOp.MAX, group=self.group)
+            guard = F.recurrence_status.finish_step(x.device, reduce)
+            if guard is None:       # (also what an optimizer_factory's object without the argument gets)
+                self.opt.step(grad_scale=1.0 / self.world)
+            else:
+                self.opt.step(grad_scale=1.0 / self.world, guard=guard)
         return loss.detach()
 
     def global_loss(self, loss: torch.Tensor) -> torch.Tensor:

@@ -143,11 +143,19 @@ class Adam:
             self.step_state = torch.zeros(2, dtype=torch.int64, device=self.flat.data.device)
             self.step_state[0] = self.step_count
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def step(self, grad_scale: float = 1.0, guard: Optional[torch.Tensor] = None) -> None:
+        """``guard``: int32 device tensor (at most 64 words); the update is skipped, on the device, if any word is
+        non-zero when the kernel runs (vts_adam_step_guarded)."""
         lib = L.load()
         f = self.flat
         if f.pending:
             f.gather_grads()
+        if guard is not None and self.step_state is None:
+            self.step_count += 1
+            L.check(lib.vts_adam_step_guarded(L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                                              f.numel, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                              grad_scale, L.wptr(guard), guard.numel(), L.stream()), "vts_adam_step_guarded")
+            return
         if self.step_state is not None:
             L.check(lib.vts_adam_step_counted(L.ptr(f.data), L.ptr(f.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                               f.numel, L.wptr(self.step_state), self.lr, self.betas[0], self.betas[1],
@@ -169,10 +177,11 @@ def forward_loss(model: nn.Module, x: torch.Tensor, y: torch.Tensor,
 
 
 def raise_on_recurrence_timeout() -> None:
-    """Raises vts.RecurrenceTimeout if a cooperative recurrent kernel of this step timed out waiting for a peer
-    workgroup (its outputs are then NaN); called before the optimizer update so that the parameters stay intact.
-    Costs one host synchronisation in steps that ran such a kernel (bf16x3, hidden 256), nothing otherwise;
-    vts.set_status_checks(False) turns it off."""
+    """Raises vts.RecurrenceTimeout if a cooperative recurrent kernel of this or an earlier step timed out waiting
+    for a peer workgroup (its outputs are then NaN).  Synchronises with the device.  train_step and
+    DataParallelTrainer do not call it: they guard the optimizer update on the device (the step's status words go
+    to vts_adam_step_guarded) and raise from a later step, when the words have reached the host; call this at the
+    end of training, or wherever a step's verdict is wanted at once.  vts.set_status_checks(False) turns both off."""
     from . import functional as F
     F.recurrence_status.raise_on_timeout()
 
@@ -191,8 +200,7 @@ def train_step(model: nn.Module, opt: Optional[Adam], x: torch.Tensor, y: torch.
     loss = forward_loss(model, x, y, noise)
     loss.backward()
     if opt is not None:
-        raise_on_recurrence_timeout()
-        opt.step()
+        opt.step(guard=F.recurrence_status.finish_step(x.device))
     return loss.detach()
 
 
