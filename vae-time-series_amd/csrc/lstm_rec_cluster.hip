@@ -757,7 +757,7 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
     if (e != hipSuccess) {
       (void)hipGetLastError();
       vts_set_error("lstm_rec3c_fwd: cooperative launch refused: %s", hipGetErrorString(e));
-      return e == hipErrorCooperativeLaunchTooLarge ? VTS_ERR_UNSUPPORTED : VTS_ERR_HIP;
+      return VTS_ERR_UNSUPPORTED;      // whatever the reason (too large, another process holds the device's cooperative queue): nothing was launched, the caller runs the kernel that waits for nobody
     }
     return VTS_OK;
   }
@@ -815,7 +815,7 @@ int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, co
     if (e != hipSuccess) {
       (void)hipGetLastError();
       vts_set_error("lstm_rec3c_bwd: cooperative launch refused: %s", hipGetErrorString(e));
-      return e == hipErrorCooperativeLaunchTooLarge ? VTS_ERR_UNSUPPORTED : VTS_ERR_HIP;
+      return VTS_ERR_UNSUPPORTED;      // whatever the reason (too large, another process holds the device's cooperative queue): nothing was launched, the caller runs the kernel that waits for nobody
     }
     return VTS_OK;
   }

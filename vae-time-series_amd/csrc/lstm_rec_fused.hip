@@ -590,7 +590,7 @@ int launch_fused(const gp::SeqPlanes& xp, float* G, float* cseq, float* hseq, fl
   if (e != hipSuccess) {
     (void)hipGetLastError();
     vts_set_error("lstm_fused_fwd: cooperative launch refused: %s", hipGetErrorString(e));
-    return e == hipErrorCooperativeLaunchTooLarge ? VTS_ERR_UNSUPPORTED : VTS_ERR_HIP;
+    return VTS_ERR_UNSUPPORTED;      // whatever the reason (too large, another process holds the device's cooperative queue): nothing was launched, the caller runs the kernel that waits for nobody
   }
   return VTS_OK;
 }
