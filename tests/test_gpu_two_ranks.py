@@ -8,9 +8,9 @@ with device tensors (an RCCL group cannot hold two ranks of one device; the trai
 * a recurrence that times out on ONE rank (the library's test hook, set in that process only): the gradient
   all-reduce spreads its NaN to both, the MAX-reduced status words stop the update on both, and both raise
   vts.RecurrenceTimeout.
-Two processes cannot both hold the device's cooperative queue: the runtime refuses the cooperative launches of one
-of them, which the library answers with the one-workgroup kernels; the cluster forward kernel is launched plainly
-here (VTS_LSTM_CLUSTER_COOP=0: sixteen workgroups in all are resident anyway), so that the hand-off path runs.
+(Launched cooperatively - VTS_LSTM_CLUSTER_COOP=1 - the recurrences of one of the two processes would be refused:
+a device has one cooperative queue.  The library answers a refusal with the one-workgroup kernels; the default
+plain launches are not affected.)
 Reference call sites: the train loop of vae-models/mixture-vae-DE.py:158-164 around nn.LSTM (:45,60)."""
 import os
 import socket
@@ -49,7 +49,6 @@ def _inputs():
 
 def _worker(rank, world, port, fault_rank, ret):
     _paths()
-    os.environ["VTS_LSTM_CLUSTER_COOP"] = "0"
     import vts
     from vts import _lib
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)

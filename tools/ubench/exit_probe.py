@@ -3,8 +3,9 @@ through torch alone, optionally with libvts_hip.so loaded (and never called) or 
 memory map before it exits, so the crash report's addresses can be matched to libraries.
 
     rocprofv3 --kernel-trace --stats -d DIR -o p --output-format csv -- python3 tools/ubench/exit_probe.py MODE MAPS
-    MODE: torch | load | call | coop | nocoop   (coop: a shape that takes the cooperative launches; nocoop: the same
-    shape with VTS_LSTM_CLUSTER_COOP=0 VTS_LSTM_PAIR_BWD=0 in the environment, i.e. plain launches only)
+    MODE: torch | load | call | coop | nocoop   (coop: a shape that takes the cluster / pair recurrences, launched
+    cooperatively - VTS_LSTM_CLUSTER_COOP=1 VTS_LSTM_PAIR_COOP=1 in the environment; nocoop: the same shape with the
+    default plain launches)
 """
 import os
 import sys

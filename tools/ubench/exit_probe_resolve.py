@@ -4,7 +4,7 @@ import re
 import sys
 
 top = sys.argv[1]
-for mode in ("torch", "load", "call", "coop", "nocoop", "bench"):
+for mode in ("torch", "load", "call", "coop", "nocoop", "bench", "benchcoop"):
     err, maps = os.path.join(top, mode + ".err"), os.path.join(top, mode + ".maps")
     if not (os.path.exists(err) and os.path.exists(maps)):
         print(f"== {mode}: files missing")

@@ -697,13 +697,16 @@ extern "C" void vts_debug_set_cluster_fault(int member) { g_fault_member.store(m
 size_t vts_lstm_rec3c_xchg_bytes(int B) { return (size_t)(B / CROWS) * X_CLUSTER; }
 size_t vts_lstm_rec3c_flag_bytes(int B) { return ((size_t)(B / CROWS) * NC + 1) * FLAG_STRIDE * sizeof(unsigned); }
 
-// Returns VTS_OK, an error, or VTS_ERR_UNSUPPORTED when the runtime will not guarantee that the whole grid is
-// resident at once (another tenant on the device, a CU mask, too few CUs) or the stream is recording a graph: the
-// caller then takes the one-workgroup kernel.  The occupancy and capture tests refuse before anything is enqueued;
-// a refusal by the cooperative launch itself comes after the packing kernel is in the queue, which has then
-// overwritten Wp, the flags and the status word - harmless, because the fall-back kernel packs Wp again and the
-// caller clears the status word.  The launch is a cooperative one for exactly that guarantee: the members of a
-// cluster wait for each other, so a grid that is only partly resident would spin until the polls time out.
+// Returns VTS_OK, an error, or VTS_ERR_UNSUPPORTED when the whole grid cannot be resident at once (the occupancy query
+// says so: a CU mask, too few CUs) or the stream is recording a graph: the caller then takes the one-workgroup
+// kernel.  Both tests refuse before anything is enqueued.  The launch is a plain one by default.  A cooperative
+// launch (VTS_LSTM_CLUSTER_COOP=1) adds nothing the occupancy query has not already established - the runtime's test
+// is the same static one; neither form reserves the compute units against kernels of other queues, which is what the
+// bounded polls and the status word are for - and costs 12 us of idle device in front of and behind the kernel (it
+// travels through a queue of its own), is refused to every process but one per device, and makes rocprofv3 runs end
+// in a segmentation fault inside the runtime's exit handler.  A refusal by the cooperative launch comes after the
+// packing kernel is in the queue, which has then overwritten Wp, the flags and the status word - harmless, because
+// the fall-back kernel packs Wp again and the caller clears the status word.
 int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* clast, const float* W_hh, float* Wp,
                        void* xws, void* fws, unsigned* err, int B, int T, void* h_planes, hipStream_t stream) {
   const int nclusters = B / CROWS;
@@ -715,14 +718,15 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
   static vts_lds_mask lds_done{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), C_LDS, &lds_done, "lstm_rec3c_fwd"))
     return rc;
-  static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return !(e && e[0] == '0'); }();
+  static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return e && e[0] == '1'; }();
   const unsigned grid = 64 * vts_cdiv(nclusters, 8);
-  if (coop) {
+  {
     if (vts_stream_is_capturing(stream)) {
-      vts_set_error("lstm_rec3c_fwd: cooperative launches cannot be recorded into a graph");
+      vts_set_error("lstm_rec3c_fwd: not recorded into graphs (a replayed grid's residency cannot be checked here)");
       return VTS_ERR_UNSUPPORTED;
     }
-    // what the runtime would refuse at launch, asked beforehand so that nothing has been enqueued on a refusal
+    // the whole grid must fit the device at once (what a cooperative launch would be refused for), asked beforehand
+    // so that nothing has been enqueued on a refusal
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -807,7 +811,7 @@ int vts_lstm_rec3c_bwd(const float* G, const float* cseq, const float* dhseq, co
   int spin_limit = mute_member >= 0 ? 1 << 10 : 1 << 21;
   int nc = nclusters;
   gp::SeqPlanes dgp{reinterpret_cast<char*>(dg_planes), 32, T, 0};
-  static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return !(e && e[0] == '0'); }();
+  static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return e && e[0] == '1'; }();
   if (coop) {
     void* args[] = {&G, &cseq, &dhseq, &dhlast, &dclast, &dbpart, &img, &dgp, &flags, &err, &T, &nc, &spin_limit, &mute_member};
     const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_rec3c_bwd_kernel), dim3(grid),

@@ -595,9 +595,11 @@ int vts_lstm_rec3p_bwd(const float* G, const float* cseq, const float* dhseq, co
     return VTS_ERR_UNSUPPORTED;
   }
   if (vts_stream_is_capturing(stream)) {
-    vts_set_error("lstm_rec3p_bwd: cooperative launches cannot be recorded into a graph");
+    vts_set_error("lstm_rec3p_bwd: not recorded into graphs (a replayed grid's residency cannot be checked here)");
     return VTS_ERR_UNSUPPORTED;
   }
+  // plain launch by default; VTS_LSTM_PAIR_COOP=1 makes it a cooperative one (see vts_lstm_rec3c_fwd for what that buys)
+  static const bool coop = [] { const char* e = getenv("VTS_LSTM_PAIR_COOP"); return e && e[0] == '1'; }();
   u32x4* img = reinterpret_cast<u32x4*>(Wp);
   // (the packing kernel also sets every word of the exchange buffer to EMPTY and clears the launch's status word)
   if (!vts_aligned16(xws)) {
@@ -612,6 +614,16 @@ int vts_lstm_rec3p_bwd(const float* G, const float* cseq, const float* dhseq, co
   int np = npairs;
   gp::SeqPlanes dgp{reinterpret_cast<char*>(dg_planes), 32, T, 0};
   unsigned char* xchg = reinterpret_cast<unsigned char*>(xws);
+  if (!coop) {
+    if (dhseq != nullptr)
+      hipLaunchKernelGGL(lstm_rec3p_bwd_kernel<true>, dim3(grid), dim3(256), P_LDS, stream, G, cseq, dhseq, dhlast, dclast, dbpart,
+                         img, dgp, xchg, err, T, np, spin_limit, mute_member);
+    else
+      hipLaunchKernelGGL(lstm_rec3p_bwd_kernel<false>, dim3(grid), dim3(256), P_LDS, stream, G, cseq, dhseq, dhlast, dclast, dbpart,
+                         img, dgp, xchg, err, T, np, spin_limit, mute_member);
+    VTS_CHECK_LAUNCH("lstm_rec3p_bwd");
+    return VTS_OK;
+  }
   void* args[] = {&G, &cseq, &dhseq, &dhlast, &dclast, &dbpart, &img, &dgp, &xchg, &err, &T, &np, &spin_limit, &mute_member};
   const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(256), args, P_LDS, stream);
   if (e != hipSuccess) {
