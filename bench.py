@@ -73,13 +73,21 @@ def parse():
                          "shapes whose eager step is bound by the host's launch rate; single process, LSTM models")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="windows in the CPU baseline sample")
-    ap.add_argument("--traffic", action="store_true",
+    ap.add_argument("--traffic", action="store_true", default=None,
                     help="also measure roofline.traffic: two short child runs of this script under rocprofv3 --pmc "
-                         "(FETCH_SIZE, WRITE_SIZE), started before this process touches the GPU; adds about a minute")
+                         "(FETCH_SIZE, WRITE_SIZE), started before this process touches the GPU; adds about twenty "
+                         "seconds.  Default: on for the full-report single-GPU run of the headline workload (LSTM models, "
+                         "LD2011 shape, bf16x3, CPU baseline leg included, no --graph, not under a profiler), off otherwise")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false", help="leave roofline.traffic null")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     dT, dC, dH = (16, 1, 64) if a.shape == "hurricane" else (96, 370, 256)
     a.T, a.C, a.H = a.T or dT, a.C or dC, a.H or dH
+    if a.traffic is None:
+        # (not under a profiler already: its preloaded tool library would travel into the child runs)
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        a.traffic = (a.gpus == 1 and a.model != "transformer" and a.shape != "hurricane" and a.mode == "bf16x3" and
+                     not a.graph and not a.traffic_child and not a.no_cpu_baseline and not profiled)
     return a
 
 

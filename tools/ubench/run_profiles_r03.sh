@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
 run() { out=$1; shift; lim=$1; shift; if ! timeout -k 10 $lim "$@" > $O/$out 2> $O/$out.err; then echo "FAILED: $*"; tail -5 $O/$out.err; exit 1; fi; }
-run r03_bench_mixture_bf16x3.json 600 python bench.py --traffic
+run r03_bench_mixture_bf16x3.json 600 python bench.py
 echo mix done
 run r03_bench_mixture_f32.json 200 python bench.py --mode f32 --no-cpu-baseline
 run r03_bench_gaussian_bf16x3.json 200 python bench.py --model gaussian --no-cpu-baseline
