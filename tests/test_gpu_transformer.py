@@ -339,6 +339,44 @@ def test_feed_forward_backward_by_recomputation(M, how):
         assert l2_rel(a, b) < 1e-5, (nm, l2_rel(a, b))
 
 
+def test_feed_forward_recomputation_small_width_and_strided_input():
+    """dim_feedforward 256 (one chunk group) and an input that is a strided view (row stride 128 floats): the
+    recomputing path against float64 torch."""
+    import vts
+    from vts import functional as Fn
+    dev = _dev()
+    M, d, F, p = 5000, 64, 256, 0.25
+    g = torch.Generator().manual_seed(77)
+    wide = torch.randn(M, 2 * d, generator=g)
+    w1 = 0.1 * torch.randn(F, d, generator=g) / math.sqrt(d)
+    b1 = (1.0 + 0.2 * torch.rand(F, generator=g)) * torch.sign(torch.randn(F, generator=g))      # pre-activations away from 0
+    w2, b2 = torch.randn(d, F, generator=g) / math.sqrt(F), torch.randn(d, generator=g) * 0.1
+    dy = torch.randn(M, d, generator=g)
+    seed = 31337
+    vts.set_mode("bf16x3")
+    try:
+        keep = Fn.dropout_mask(seed, p, (M, F), dev).cpu().double()
+        ref_in = [t.double().requires_grad_(True) for t in (wide, w1, b1, w2, b2)]
+        hid = torch.relu(torch.nn.functional.linear(ref_in[0][:, :d], ref_in[1], ref_in[2])) * keep / (1 - p)
+        y_ref = torch.nn.functional.linear(hid, ref_in[3], ref_in[4])
+        y_ref.backward(dy.double())
+        wd = wide.to(dev).requires_grad_(True)
+        params = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
+        xv = wd[:, :d]
+        assert xv.stride(0) == 2 * d
+        from vts import _lib
+        assert _lib.load().vts_ffn_recompute_supported(xv.data_ptr(), xv.stride(0), M, d, F, 1) == 1
+        y = Fn.feed_forward(xv, *params, None, p, seed)
+        y.backward(dy.to(dev))
+    finally:
+        vts.set_mode("f32")
+    assert l2_rel(y, y_ref) < 2e-5
+    assert l2_rel(wd.grad[:, :d], ref_in[0].grad[:, :d]) < 2e-5
+    assert wd.grad[:, d:].abs().max().item() == 0
+    for a, b, nm in zip(params, ref_in[1:], ["w1", "b1", "w2", "b2"]):
+        assert l2_rel(a.grad, b.grad) < 2e-5, (nm, l2_rel(a.grad, b.grad))
+
+
 def test_large_batch_bf16x3_matches_oracle():
     """Enough windows that the layer's products run on the split-bf16 kernels."""
     import vts
