@@ -215,6 +215,12 @@ int vts_lstm_wgrad_planes(const void* dg_planes, const void* x_planes, int x_is_
 /* Test hook, process-wide: member `member` (0..7) of every cluster of the bench-sized forward recurrence withholds
  * its hand-off flags and the waits are cut short, so the timeout path above can be exercised; -1 = off (default). */
 void vts_debug_set_cluster_fault(int member);
+/* Development switch, process-wide: which forward cluster kernel runs the bench-sized forward recurrence.  on != 0:
+ * one ring of eight WAVES per window tile (wave w of each of the cluster's eight workgroups; two waves per SIMD, no
+ * workgroup barrier inside the time loop, every wave publishes and polls for its own 16 windows); on = 0: the
+ * workgroup-wide hand-off (one wave per SIMD, one flag per workgroup and step).  Start-up value from
+ * VTS_LSTM_CLUSTER_RINGS.  Same arithmetic in the same order: identical results. */
+void vts_debug_set_cluster_rings(int on);
 /* Development switch, process-wide: on != 0 lets vts_lstm_recurrent_bwd_planes run the bench-sized backward
  * recurrence as clusters of eight workgroups with W_hh stationary (the forward pass always does); off (default,
  * unless VTS_LSTM_CLUSTER_BWD=1 is set at start-up) it runs one workgroup per 16 windows, which measures 3 %

@@ -251,3 +251,70 @@ def test_fused_forward_with_a_missing_peer(fused_forward):
     _, (again, _) = lstm(x, need_output=False)
     assert torch.equal(again, good)
     assert all(v == 0 for _, v in vts.recurrence_status.read())
+
+
+# ---- forward cluster kernel with one ring of waves per window tile (vts_debug_set_cluster_rings) --------------------
+def _ring_case(rings, B, T, C, layers, need_output, fault=-1, odd_route=False):
+    """Forward + backward of a vts.LSTM whose forward recurrence runs on the chosen cluster kernel.  odd_route: fp32
+    rows in and out (no plane output; an odd step count keeps the layer off the plane path), so that the members
+    exchange h through the two alternating exchange buffers instead of the plane buffer."""
+    import vts
+    from vts import _lib
+    lib = _lib.load()
+    dev = _dev()
+    torch.manual_seed(17)
+    lstm = vts.LSTM(C, 256, num_layers=layers).to(dev)
+    x = torch.randn(B, T, C, device=dev)
+    assert _planes_taken(B, T, C, 256) != odd_route
+    lib.vts_debug_set_cluster_rings(rings)
+    lib.vts_debug_set_cluster_fault(fault)
+    try:
+        out, (hn, cn) = lstm(x, need_output=need_output)
+        loss = hn.pow(2).sum() + (cn * 0.5).sum() + (out.pow(2).sum() if need_output else 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.vts_debug_set_cluster_rings(0)
+        lib.vts_debug_set_cluster_fault(-1)
+    res = {"hn": hn.detach().clone(), "cn": cn.detach().clone(), "out": out.detach().clone()}
+    res.update({k: p.grad.clone() for k, p in lstm.named_parameters()})
+    return res, lstm, x
+
+
+@pytest.mark.parametrize("B,T,C,layers,need_output,odd_route", [
+    (128, 2, 8, 1, True, False),       # one cluster, the shortest sequence that has a hand-off
+    (256, 16, 370, 3, False, False),   # two clusters, three layers, plane output only
+    (1024, 8, 256, 2, True, False),    # eight clusters = one per XCD
+    (128, 7, 8, 2, True, True),        # odd step count: the tail step of the two-step loop, exchange buffers
+    (384, 5, 64, 1, False, True),
+])
+def test_wave_ring_forward_is_bit_identical(B, T, C, layers, need_output, odd_route):
+    """Both forward cluster kernels do the same arithmetic in the same order - same fragments, same accumulation
+    order, same cell update - so every output and, through the saved tensors, every gradient must be bit-identical;
+    and the ring kernel's result is held to torch's CPU nn.LSTM like everything else."""
+    base, _, _ = _ring_case(0, B, T, C, layers, need_output, odd_route=odd_route)
+    ring, lstm, x = _ring_case(1, B, T, C, layers, need_output, odd_route=odd_route)
+    for k in base:
+        assert torch.equal(base[k], ring[k]), k
+    ref = torch.nn.LSTM(C, 256, num_layers=layers, batch_first=True)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in lstm.state_dict().items()})
+    out_r, (hn_r, cn_r) = ref(x.cpu())
+    assert l2_rel(ring["hn"], hn_r) < TOL and l2_rel(ring["cn"], cn_r) < TOL
+    if need_output:
+        assert l2_rel(ring["out"], out_r) < TOL
+
+
+def test_wave_ring_forward_with_a_missing_peer():
+    """A member whose waves never raise their flags: every ring gives up after its bounded wait, the final state is NaN
+    and the status word is set; the next launch is clean."""
+    import vts
+    good, _, _ = _ring_case(1, 128, 6, 8, 2, True)
+    vts.raise_on_recurrence_timeout()            # clean so far
+    bad, _, _ = _ring_case(1, 128, 6, 8, 2, True, fault=3)
+    assert torch.isnan(bad["hn"]).any(), "a missed hand-off must poison the final state"
+    with pytest.raises(vts.RecurrenceTimeout, match="lstm_rec3c_fwd_kernel"):
+        vts.raise_on_recurrence_timeout()
+    again, _, _ = _ring_case(1, 128, 6, 8, 2, True)
+    vts.raise_on_recurrence_timeout()
+    for k in good:
+        assert torch.equal(good[k], again[k]), k

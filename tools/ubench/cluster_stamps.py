@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vae-time-series_amd"))
 import torch
 from vts import _lib as L
-L.LIB_PATH = os.path.join(ROOT, "tools", "ubench", "libvts_cstamp.so")
+L.LIB_PATH = os.path.join(ROOT, "tools", "ubench", os.environ.get("CSTAMP_LIB", "libvts_cstamp.so"))
 lib = L.load()
 dev = torch.device("cuda:0")
 B, T, H = 4096, 96, 256
@@ -23,7 +23,9 @@ for it in range(3):
     else:
         L.check(lib.vts_lstm_recurrent_fwd(L.wptr(gates), L.wptr(cells), L.ptr(hseq), L.ptr(h_last), None, L.ptr(w_hh), L.wptr(ws), wsb, B, T, H, 1, L.stream()), "fwd")
 torch.cuda.synchronize()
-off = wsb - 256 - ((B // 16) * 512 + 255) // 256 * 256     # the launch's status word; the stamps follow it
+r256 = lambda n: (n + 255) // 256 * 256
+# the launch's status word (behind the packed image, the bias partials and the two final-state seeds); the stamps follow it
+off = r256(4 * H * H * 4) + r256(B // 16 * 4 * H * 4) + 2 * r256(B * H * 4)
 raw = ws[off:off + 128].cpu()
 print("err word", raw[:4].view(torch.int32).item())
 st = raw[8:72].view(torch.int64).tolist()

@@ -312,6 +312,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 vts_lds_mask g_lds_row{0}, g_lds_wgrad{0};
 
 int grid_cus() {
+  // development switch: the persistent grids sized for a share of the device (two half batches side by side)
+  if (const char* e = getenv("VTS_GRID_CUS")) {
+    const int want = atoi(e);
+    if (want >= 8 && want <= 1024 && want % 8 == 0) return want;
+  }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

@@ -400,6 +400,276 @@ __global__ __launch_bounds__(256) void lstm_rec3c_fwd_kernel(
 }
 
 
+// ---- forward, one ring of waves per window tile -------------------------------------------------------------------
+// Same clusters, same slices, same buffers as lstm_rec3c_fwd_kernel, other division of labour.  The recurrence of a
+// window tile (16 windows) needs nothing of the cluster's other seven tiles, so the unit that takes part in a
+// hand-off is a WAVE, not a workgroup: wave w of member c owns window tile w of the cluster for the member's 128 gate
+// columns, publishes its own 1 KiB block of h_t (both planes) and raises a flag of its own; it waits for the eight
+// waves w of the cluster's members and for nobody else.  A workgroup is eight such waves, two per SIMD, and has no
+// barrier inside the time loop: while one wave of a SIMD waits for its ring (flag, fragments from the L2, write
+// acknowledgements) the other one has the matrix core.  In the kernel above those waits - a third of its step - sit
+// on the critical path of the one wave a SIMD runs.  The price: every wave reads the whole resident slice from LDS
+// for one window tile instead of two (3 MFMAs per fragment pair instead of 6).
+// flags: [cluster][window tile w] lines of FLAG_STRIDE words, word c = number of steps member c's wave w published.
+#ifndef VTS_W_ST_KS
+#define VTS_W_ST_KS 4      // k-steps over which the previous step's bulk stores are spread (2 or 4); the gate loads follow
+#endif
+__global__ __launch_bounds__(512) void lstm_rec3w_fwd_kernel(
+    float* __restrict__ G, float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hlast,
+    float* __restrict__ clast, const u32x4* __restrict__ Wp, u64* __restrict__ xchg, unsigned* __restrict__ flags,
+    unsigned* __restrict__ err, int T, int nclusters, int spin_limit, int mute_member, gp::SeqPlanes hp) {
+  constexpr int JT = CH / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemc[];
+  u32x4* wl = reinterpret_cast<u32x4*>(smemc);                 // [ks][plane][ct][lane]
+  unsigned char* stage = smemc + W_LDS;                        // [plane][128 rows][64 B]; wave w owns rows 16w .. 16w + 15
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = window tile of the cluster
+  const int r = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int c = j & 7;
+  const int q = (j >> 3) * 8 + xcd;
+  if (q >= nclusters) return;
+  {
+    const u32x4* src = Wp + (size_t)c * (W_LDS / 16);
+#pragma unroll 4
+    for (int i = tid; i < W_LDS / 16; i += 512) wl[i] = src[i];
+  }
+  const bool planes = hp.base != nullptr;
+  const long hp_cluster_bytes = 8L * hp.ts * hp.ncb * 2 * gp::TILE_B;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      planes ? __builtin_amdgcn_make_buffer_rsrc(hp.base + hp.tile((long)q * 8, -hp.t0, 0, 0), 0, (int)hp_cluster_bytes, 0x00020000)
+             : __builtin_amdgcn_make_buffer_rsrc(xchg + (size_t)q * (X_CLUSTER / 8), 0, (int)X_CLUSTER, 0x00020000);
+  // byte offset, in xrsrc, of the 1 KiB block (this wave's window tile, column block / k-step ks, plane p) of h_t:
+  // xbase(t) + ks * kstr + p * pstr in both media (plane buffer: every step its own slot; exchange buffer: two
+  // buffers that alternate with the step's parity)
+  const int kstr = planes ? 2 * gp::TILE_B : 1024, pstr = planes ? gp::TILE_B : X_PLANE;
+  auto xbase = [&](int t) -> int {
+    return planes ? ((wave * hp.ts + hp.t0 + t) * hp.ncb) * (2 * gp::TILE_B) : (t & 1) * (2 * X_PLANE) + wave * KS * 1024;
+  };
+  unsigned* fq = flags + ((size_t)q * NC + wave) * FLAG_STRIDE;
+  const long bt = (long)q * 8 + wave;
+  const unsigned pl_off = gp::slot(g, r) * 16;
+  if (planes) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      *reinterpret_cast<u32x4*>(hp.base + hp.tile(bt, -1, c, p) + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  f32x4 cst[2];
+  cst[0] = cst[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The tile16 blocks of this wave's window tile (gates: T x 64 blocks, cells: T x 16 blocks of 1 KiB) as buffer
+  // resources: a block's address is then a scalar offset plus lane * 16, and no vector register holds an address.
+  const __amdgpu_buffer_rsrc_t grsrc =
+      __builtin_amdgcn_make_buffer_rsrc(G + bt * T * (4 * JT) * 256, 0, T * (4 * JT) * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crsrc =
+      __builtin_amdgcn_make_buffer_rsrc(cseq + bt * T * JT * 256, 0, T * JT * 1024, 0x00020000);
+  const int lane16 = lane * 16;
+  const int xvoff = planes ? (int)pl_off : lane16;        // a lane's 16 bytes inside a 1 KiB block of the exchange medium
+  auto gblock = [&](int t, int gate, int jl) -> int { return (t * (4 * JT) + gate * JT + 2 * c + jl) * 1024; };
+  // Two gate buffers that swap roles every step: `acc` enters a step holding the step's gate pre-activations
+  // (fetched during the step before), receives the recurrent product and is turned into the gate activations in
+  // place by the cell update; `nxt` enters holding the activations of the step before, which leave for memory during
+  // the first half of the product, and is then refilled with the next step's pre-activations.
+  f32x4 bufa[CT], bufb[CT];
+  auto load_g_one = [&](f32x4 (&dst)[CT], int t, int ct) {      // streaming (nt) load, as ld_stream
+    dst[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16, gblock(t, ct >> 1, ct & 1), 2));
+  };
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) load_g_one(bufa, 0, ct);
+  __syncthreads();   // the image slice is in place; the only workgroup barrier of the kernel
+
+  // an eighth of a step's bulk stores: sub = jl*4 + {1: gates i f, 2: gates g o, 3: cell block} (0: nothing - the
+  // fp32 rows of h, where a caller wants them, leave straight from the cell update)
+  auto store_part = [&](const f32x4 (&act)[CT], int t, int sub) {
+    const int jl = sub >> 2, what = sub & 3;
+    const int jt = 2 * c + jl;
+    if (what == 3) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, cst[jl]), crsrc, lane16, (t * JT + jt) * 1024, 0);
+    } else if (what != 0) {
+#pragma unroll
+      for (int gate = 2 * (what - 1); gate < 2 * what; ++gate)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, act[gate * 2 + jl]), grsrc, lane16, gblock(t, gate, jl), 0);
+    }
+  };
+#ifdef VTS_C_STAMP
+  long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#endif
+  // one time step; false when the ring gave up waiting for a peer
+  auto step = [&](int t, f32x4 (&acc)[CT], f32x4 (&nxt)[CT]) -> bool {
+    STAMP(6);
+    u32x4 a[KS][2];      // the fragments of h_{t-1} for this wave's window tile, all k-steps, both planes
+    if (t > 0) {
+#ifndef VTS_C_NOSYNC
+      int spins = 0;
+      bool ok = false;
+      do {
+        const unsigned seen = lane < NC ? __hip_atomic_load(fq + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        ok = __all(seen >= (unsigned)t);
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+      } while (++spins < spin_limit);
+      if (!ok) {
+        if (lane == 0) atomicOr(err, 1u);
+        return false;
+      }
+#endif
+      // Nothing that reads the peers' blocks may be issued before the flags were seen: the loop above has consumed the
+      // flag loads, instructions issue in order, and the fragment loads below are sc1 accesses that go to the L2 like
+      // the flag loads did - so a compiler barrier is all that is needed.  (An agent-scope acquire fence would be a
+      // buffer_inv sc1, which on this multi-XCD part also drops lines from the L2: measured 5 000 - 8 000 ticks per
+      // step and wave, and every other access of the kernel slowed down with it.)
+      asm volatile("" ::: "memory");
+      STAMP(0);
+      // Every fragment load of the step goes out now, in front of the step's other memory traffic: vector memory
+      // operations complete in issue order, and a fragment queued behind a store's write acknowledgement or a gate
+      // block from HBM would hold up the product for that long.
+      const int xin = xbase(t - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          a[ks][p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xvoff, xin + ks * kstr + p * pstr, 16));
+      STAMP(1);
+    }
+    if (t == 0) {
+      if (T > 1) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) load_g_one(nxt, 1, ct);
+      }
+    } else {
+      // 32 groups of six MFMAs, one per (k-step, pair of column tiles): the two tiles alternate, so that an MFMA never
+      // follows the one whose accumulator it adds to.  W fragments are read from LDS one group ahead (the SIMD's other wave covers what that leaves).
+      u32x4 bh[2][2], bl[2][2];
+      const int tnext = min(t + 1, T - 1);
+      auto fetch_b = [&](int idx, int slot) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          bh[slot][e] = wl[(((idx >> 2) * 2 + 0) * CT + 2 * (idx & 3) + e) * 64 + lane];
+          bl[slot][e] = wl[(((idx >> 2) * 2 + 1) * CT + 2 * (idx & 3) + e) * 64 + lane];
+        }
+      };
+      fetch_b(0, 0);
+#ifdef VTS_W_NOLDS
+      fetch_b(1, 1);
+#endif
+      static_for<KS * CT / 2>([&](auto idx_c) {
+        constexpr int idx = decltype(idx_c)::value;
+        constexpr int ks = idx >> 2, cp = idx & 3, slot = idx & 1;
+#ifndef VTS_W_NOLDS
+        if (idx + 1 < KS * CT / 2) fetch_b(idx + 1, (idx + 1) & 1);
+#endif
+        // the previous step's bulk stores over the first four k-steps, then the next step's gate pre-activations
+        // into the registers they left (the last step re-reads its own blocks: no branch here)
+#ifndef VTS_C_NOSTORE
+#ifndef VTS_W_NOST
+        if (ks < VTS_W_ST_KS) { if (cp % (VTS_W_ST_KS / 2) == 0 || VTS_W_ST_KS == 2) store_part(nxt, t - 1, ks * (8 / VTS_W_ST_KS) + (VTS_W_ST_KS == 2 ? cp : cp / (VTS_W_ST_KS / 2))); }
+#endif
+#ifndef VTS_W_NOG
+        if (ks == VTS_W_ST_KS || ks == VTS_W_ST_KS + 1) load_g_one(nxt, tnext, (ks - VTS_W_ST_KS) * 4 + cp);
+#endif
+#endif
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          acc[2 * cp + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][1]), frag(bh[slot][e]), acc[2 * cp + e], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          acc[2 * cp + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][0]), frag(bl[slot][e]), acc[2 * cp + e], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          acc[2 * cp + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(a[ks][0]), frag(bh[slot][e]), acc[2 * cp + e], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    STAMP(2);
+    // cell update, lane-local and in place: acc[gate*2 + jl][reg] is gate `gate` of window row 4g + reg, hidden unit
+    // (2c + jl)*16 + r, and holds the gate's activation afterwards
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const float gi = fast_sigmoid(acc[0 + jl][reg]);
+        const float gf = fast_sigmoid(acc[2 + jl][reg]);
+        const float gg = fast_tanh(acc[4 + jl][reg]);
+        const float go = fast_sigmoid(acc[6 + jl][reg]);
+        acc[0 + jl][reg] = gi; acc[2 + jl][reg] = gf; acc[4 + jl][reg] = gg; acc[6 + jl][reg] = go;
+        cst[jl][reg] = gf * cst[jl][reg] + gi * gg;
+        const float h = go * fast_tanh(cst[jl][reg]);
+        {
+          const long b = bt * 16 + 4 * g + reg;
+          const int col = (2 * c + jl) * 16 + r;
+          if (hseq != nullptr) hseq[(b * T + t) * CH + col] = h;
+          if (t == T - 1) {
+            if (hlast != nullptr) hlast[b * CH + col] = h;
+            if (clast != nullptr) clast[b * CH + col] = cst[jl][reg];
+          }
+        }
+        const float other = lane_xor1(h);
+        const bool odd = r & 1;
+        unsigned hi, lo;
+        split2(odd ? other : h, odd ? h : other, hi, lo);
+        const int row = wave * 16 + 4 * g + reg;
+        const int col = jl * 16 + (r & ~1);
+        *reinterpret_cast<unsigned*>(stage + (odd ? S_PLANE : 0) + row * 64 + col * 2) = odd ? lo : hi;
+      }
+    STAMP(3);
+    if (t + 1 < T) {
+      // publish this wave's block of h_t (window tile w, column block c): the rows it has just written itself - LDS
+      // operations of a wave execute in order - as fragments, one KiB per plane
+      const int xout = xbase(t) + c * kstr;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + p * S_PLANE + (wave * 16 + r) * 64 + g * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bvec4, v), xrsrc, xvoff, xout + p * pstr, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the block has reached the L2 before the flag goes up
+      if (lane == 0 && c != mute_member)
+        __hip_atomic_store(fq + c, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    STAMP(4);
+    return true;
+  };
+  bool dead = false;
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    if (!step(t, bufa, bufb) || !step(t + 1, bufb, bufa)) { dead = true; break; }
+  }
+  const bool odd_T = (T & 1) != 0;
+  if (!dead && odd_T) dead = !step(T - 1, bufa, bufb);
+#ifdef VTS_C_STAMP
+  if (blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 8; ++i) reinterpret_cast<long long*>(err + 2)[i] = stamp[i];
+#endif
+  if (!dead) {
+    // the last step's activations sit in the buffer that step accumulated in
+#pragma unroll
+    for (int sub = 0; sub < 8; ++sub) {
+      if (odd_T) store_part(bufa, T - 1, sub);
+      else store_part(bufb, T - 1, sub);
+    }
+    if (planes) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        *reinterpret_cast<u32x4*>(hp.base + hp.tile(bt, T - 1, c, p) + pl_off) =
+            *reinterpret_cast<const u32x4*>(stage + p * S_PLANE + (wave * 16 + r) * 64 + g * 16);
+    }
+  } else {
+    // a peer never published: besides the error word, poison what the layers above read
+    const float poison = __builtin_nanf("");
+#pragma unroll
+    for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const long b = bt * 16 + 4 * g + reg;
+        const int col = (2 * c + jl) * 16 + r;
+        if (hseq != nullptr) hseq[(b * T + T - 1) * CH + col] = poison;
+        if (hlast != nullptr) hlast[b * CH + col] = poison;
+        if (clast != nullptr) clast[b * CH + col] = poison;
+      }
+  }
+}
+
+
 // ---- backward ---------------------------------------------------------------------------------------------
 // Reverse recurrence with W_hh stationary, same clusters: member c owns hidden units [32c, 32c + 32).  Per step it
 // turns the running gradients of its slice into the gate gradients dA_t[:, 128 columns of its slice] (cell
@@ -690,6 +960,9 @@ bool vts_lstm_rec3c_usable(int B, int T, int H) {
 // Test hook: member `member` (0..7) of every cluster withholds its flags and the polls give up after 1024 rounds, so
 // that the timeout path can be exercised; -1 (the default) = off.  Process-wide, not for production callers.
 static std::atomic<int> g_fault_member{-1};
+// Development switch: 1 = the forward cluster kernel with one ring of waves per window tile (VTS_LSTM_CLUSTER_RINGS).
+static std::atomic<int> g_wave_rings{[] { const char* e = getenv("VTS_LSTM_CLUSTER_RINGS"); return e ? atoi(e) : 0; }()};
+extern "C" void vts_debug_set_cluster_rings(int on) { g_wave_rings.store(on ? 1 : 0); }
 extern "C" void vts_debug_set_cluster_fault(int member) { g_fault_member.store(member < 0 ? -1 : (member & (NC - 1))); }
 
 // xws: exchange buffers (X_CLUSTER bytes per cluster) followed by the flags; fws: flag words; err: the launch's
@@ -715,10 +988,16 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
     vts_set_error("lstm_rec3c_fwd: %d steps are too many for the cluster kernel's plane addressing", T);
     return VTS_ERR_UNSUPPORTED;
   }
-  static vts_lds_mask lds_done{0};
+  static vts_lds_mask lds_done{0}, lds_done_w{0};
   if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), C_LDS, &lds_done, "lstm_rec3c_fwd"))
     return rc;
+  if (int rc = vts_reserve_lds(reinterpret_cast<const void*>(lstm_rec3w_fwd_kernel), C_LDS, &lds_done_w, "lstm_rec3w_fwd"))
+    return rc;
   static const bool coop = [] { const char* e = getenv("VTS_LSTM_CLUSTER_COOP"); return e && e[0] == '1'; }();
+  // which division of labour: a ring of waves per window tile (lstm_rec3w_fwd_kernel) or the workgroup-wide hand-off
+  const bool rings = g_wave_rings.load() != 0;
+  const void* kern = rings ? reinterpret_cast<const void*>(lstm_rec3w_fwd_kernel) : reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel);
+  const unsigned threads = rings ? 512 : 256;
   const unsigned grid = 64 * vts_cdiv(nclusters, 8);
   {
     if (vts_stream_is_capturing(stream)) {
@@ -730,8 +1009,7 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), 256,
-                                                     C_LDS) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int)threads, C_LDS) != hipSuccess ||
         (long)per_cu * cus < (long)grid) {
       (void)hipGetLastError();
       vts_set_error("lstm_rec3c_fwd: %u workgroups cannot be resident at once (%d per CU x %d CUs)", grid, per_cu, cus);
@@ -756,8 +1034,7 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
   gp::SeqPlanes hp{reinterpret_cast<char*>(h_planes), 8, T + 1, 1};
   if (coop) {
     void* args[] = {&G, &cseq, &hseq, &hlast, &clast, &img, &xchg, &flags, &err, &T, &nc, &spin_limit, &mute_member, &hp};
-    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_rec3c_fwd_kernel), dim3(grid),
-                                                    dim3(256), args, C_LDS, stream);
+    const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(threads), args, C_LDS, stream);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       vts_set_error("lstm_rec3c_fwd: cooperative launch refused: %s", hipGetErrorString(e));
@@ -765,8 +1042,12 @@ int vts_lstm_rec3c_fwd(float* G, float* cseq, float* hseq, float* hlast, float* 
     }
     return VTS_OK;
   }
-  hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(grid), dim3(256), C_LDS, stream, G, cseq, hseq, hlast, clast, img, xchg,
-                     flags, err, T, nclusters, spin_limit, mute_member, hp);
+  if (rings)
+    hipLaunchKernelGGL(lstm_rec3w_fwd_kernel, dim3(grid), dim3(512), C_LDS, stream, G, cseq, hseq, hlast, clast, img, xchg,
+                       flags, err, T, nclusters, spin_limit, mute_member, hp);
+  else
+    hipLaunchKernelGGL(lstm_rec3c_fwd_kernel, dim3(grid), dim3(256), C_LDS, stream, G, cseq, hseq, hlast, clast, img, xchg,
+                       flags, err, T, nclusters, spin_limit, mute_member, hp);
   VTS_CHECK_LAUNCH("lstm_rec3c_fwd");
   return VTS_OK;
 }

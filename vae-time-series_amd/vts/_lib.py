@@ -53,6 +53,7 @@ SIGNATURES = {
     "vts_lstm_recurrent_fwd": (_int, [_ptr] * 6 + [_ptr, _sz, _i64, _i64, _i64, _int, _ptr]),
     "vts_lstm_recurrent_fwd_status": (_int, [_ptr, _sz, _i64, _i64, _i64, _ptr, _ptr]),
     "vts_debug_set_cluster_fault": (None, [_int]),
+    "vts_debug_set_cluster_rings": (None, [_int]),
     "vts_debug_set_cluster_bwd": (None, [_int]),
     "vts_debug_set_staged_bwd": (None, [_int]),
     "vts_debug_set_pair_bwd": (None, [_int]),
