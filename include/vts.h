@@ -272,7 +272,7 @@ int vts_linear_bwd(const float* dy, const float* y, const float* aux, int act, f
                    vts_stream_t stream);
 
 /* act = VTS_ACT_RELU_DROPOUT with the mask drawn by the library's counter hash instead of fed in:
- * element (row, col) is kept iff hash(seed, row*N + col) >= drop_p * 2^32 and scaled by 1/(1-drop_p);
+ * element (row, col) is kept iff its 16 bits of the hash (index row*N + col, below) are >= drop_p * 2^16, and scaled by 1/(1-drop_p);
  * seed 0 or drop_p 0 = eval mode (plain relu).  Backward is vts_linear_bwd with VTS_ACT_RELU_DROPOUT and
  * keep_scale 1/(1-drop_p): it needs y only, not the mask.  Replaces dropout(relu(linear1(x))) inside
  * nn.TransformerEncoderLayer (mixture-vae-transformer.py:39) without a [tokens, 2048] mask in memory. */
@@ -422,7 +422,7 @@ int vts_mlp_chain_bwd(const vts_mlp_chain* chain, const float* x, int64_t ldx, i
  * -> vts_dropout_add_fwd -> vts_layernorm_fwd.
  *
  * Dropout sites take (keep, drop_p, seed): keep != NULL = explicit 0/1 byte mask; else seed != 0 = the
- * library's counter hash (element idx kept iff hash(seed, idx) >= drop_p * 2^32; vts_dropout_mask writes
+ * library's counter hash (element idx takes 16 bits of hash(seed, idx / 2) - the low ones if idx is even - and is kept iff they are >= drop_p * 2^16; vts_dropout_mask writes
  * that mask out); else no dropout (eval mode).  Kept elements are scaled by 1/(1-drop_p).
  *
  * vts_mha_*: softmax(q k^T / sqrt(dh)) v per (window, head), dropout on the weights.  q: Tq query rows per

@@ -101,7 +101,21 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaParams P) {
 #pragma unroll
     for (int c = 0; c < DH; ++c) acc[c] = 0.f;
     const unsigned long long mbase = ((unsigned long long)item * P.Tq + i) * P.T;
-    for (int j = 0; j < P.T; ++j) {
+    // keys two at a time where the mask index of the first is even: one hash draws both keep decisions
+    int j = 0;
+    if ((mbase & 1) == 0) {
+      for (; j + 1 < P.T; j += 2) {
+        float m0, m1;
+        P.drop.mult2(mbase + j, m0, m1);
+        const float p0 = __expf(dot<DH>(q, Ks + j * DH) - m);
+        const float p1 = __expf(dot<DH>(q, Ks + (j + 1) * DH) - m);
+        l += p0;
+        axpy<DH>(p0 * m0, Vs + j * DH, acc);
+        l += p1;
+        axpy<DH>(p1 * m1, Vs + (j + 1) * DH, acc);
+      }
+    }
+    for (; j < P.T; ++j) {
       const float p = __expf(dot<DH>(q, Ks + j * DH) - m);
       l += p;
       axpy<DH>(p * P.drop.mult(mbase + j), Vs + j * DH, acc);
@@ -154,10 +168,24 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const MhaParams P) {
 #pragma unroll
     for (int c = 0; c < DH; ++c) { q[c] *= P.scale; dq[c] = 0.f; }
     const float lse = Ls[i], D = Ds[i];
-    for (int j = 0; j < P.T; ++j) {
+    const unsigned long long mrow = (mitem + i) * P.T;
+    int j = 0;
+    if ((mrow & 1) == 0) {                         // as in the forward kernel: one hash per two keys
+      for (; j + 1 < P.T; j += 2) {
+        float m0, m1;
+        P.drop.mult2(mrow + j, m0, m1);
+        const float p0 = __expf(dot<DH>(q, Ks + j * DH) - lse);
+        const float ds0 = p0 * (m0 * dot<DH>(g, Vs + j * DH) - D);
+        axpy<DH>(ds0, Ks + j * DH, dq);
+        const float p1 = __expf(dot<DH>(q, Ks + (j + 1) * DH) - lse);
+        const float ds1 = p1 * (m1 * dot<DH>(g, Vs + (j + 1) * DH) - D);
+        axpy<DH>(ds1, Ks + (j + 1) * DH, dq);
+      }
+    }
+    for (; j < P.T; ++j) {
       const float p = __expf(dot<DH>(q, Ks + j * DH) - lse);
       const float dwd = dot<DH>(g, Vs + j * DH);
-      const float ds = p * (P.drop.mult((mitem + i) * P.T + j) * dwd - D);
+      const float ds = p * (P.drop.mult(mrow + j) * dwd - D);
       axpy<DH>(ds, Ks + j * DH, dq);
     }
 #pragma unroll
@@ -271,7 +299,7 @@ __global__ void dropout_add_kernel(const float* __restrict__ residual, const flo
 }
 __global__ void dropout_mask_kernel(unsigned long long seed, unsigned thresh, unsigned char* __restrict__ keep, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    keep[i] = vts_hash32(seed, (unsigned long long)i) >= thresh ? 1 : 0;
+    keep[i] = vts_drop_keep(seed, (unsigned long long)i, thresh) ? 1 : 0;
 }
 
 int grid_for(long n) {

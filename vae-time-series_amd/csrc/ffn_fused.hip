@@ -207,8 +207,10 @@ __global__ __launch_bounds__(512, 2) void ffn_b2b_kernel(const FfnParams P) {
           if (tok_ok) v = v * *reinterpret_cast<const f32x4*>(P.keep + mid_off + hcol) * P.scale;
         } else if constexpr (DROP == 2) {
           const unsigned long long idx = (unsigned long long)mid_off + hcol;
+          bool kp[4];
+          vts_drop_keep4(P.seed, idx, P.thresh, kp);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = vts_hash32(P.seed, idx + e) >= P.thresh ? v[e] * P.scale : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * P.scale : 0.f;
         }
       } else {
         if constexpr (BITS) {
@@ -483,8 +485,10 @@ __global__ __launch_bounds__(512) void ffn_regs_kernel(const FfnRegsParams P) {
           if constexpr (DROP == 1) {
             if (ok[T]) v = v * *reinterpret_cast<const f32x4*>(P.keep + idx) * P.scale;
           } else if constexpr (DROP == 2) {
+            bool kp[4];
+            vts_drop_keep4(P.seed, (unsigned long long)idx, P.thresh, kp);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = vts_hash32(P.seed, (unsigned long long)idx + e) >= P.thresh ? v[e] * P.scale : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * P.scale : 0.f;
           }
           if (!ok[T]) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll

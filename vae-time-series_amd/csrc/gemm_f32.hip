@@ -360,7 +360,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& P, f32x4 (&acc)[4][4]
         v = fmaxf(v, 0.f);
         if (P.keep) v = v * P.keep[off] * P.keep_scale;
         else if (P.drop_thresh)
-          v = vts_hash32(P.drop_seed, (unsigned long long)row * P.N + col) >= P.drop_thresh ? v * P.keep_scale : 0.f;
+          v = vts_drop_keep(P.drop_seed, (unsigned long long)row * P.N + col, P.drop_thresh) ? v * P.keep_scale : 0.f;
       }
       if (P.mask_src) v = (P.mask_src[(long)row * P.ld_mask + col] != 0.f) ? v * P.mask_scale : 0.f;
       if (P.accumulate) v += Cbase[off];

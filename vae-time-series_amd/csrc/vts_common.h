@@ -109,10 +109,13 @@ static __device__ __forceinline__ void split4(float x0, float x1, float x2, floa
 }
 
 // ---- counter-based dropout ----------------------------------------------------------------------
-// Element `idx` of a tensor whose mask was drawn with `seed` is kept iff vts_hash32(seed, idx) >=
-// thresh, thresh = p * 2^32.  A pure function of (seed, idx): the backward pass and any number of
-// kernels regenerate the same mask without storing it.  One round of a multiply/xor-shift mixer
-// over the low index word, with the high word and the second seed word folded in.
+// One hash serves two elements: element `idx` of a tensor whose mask was drawn with `seed` takes the low
+// (idx even) or the high (idx odd) 16 bits of vts_hash32(seed, idx >> 1) and is kept iff they are >= thresh,
+// thresh = round(p * 2^16) (the drop probability is p to within 2^-17).  A pure function of (seed, idx): the
+// backward pass and any number of kernels regenerate the same mask without storing it.  The hash is one round of a
+// multiply/xor-shift mixer over the low index word, with the high word and the second seed word folded in; its two
+// 32-bit multiplies run at a quarter of the vector rate, which is why the kernels that draw a mask per matrix-core
+// operand (the feed-forward block, the attention weights) share it between neighbours.
 __host__ __device__ static inline unsigned vts_hash32(unsigned long long seed, unsigned long long idx) {
   unsigned x = (unsigned)idx ^ (unsigned)seed;
   x += (unsigned)(idx >> 32) * 0x9E3779B9u + (unsigned)(seed >> 32);
@@ -121,10 +124,31 @@ __host__ __device__ static inline unsigned vts_hash32(unsigned long long seed, u
   x ^= x >> 16;
   return x;
 }
+__host__ __device__ static inline bool vts_drop_keep(unsigned long long seed, unsigned long long idx, unsigned thresh) {
+  const unsigned h = vts_hash32(seed, idx >> 1);
+  return ((idx & 1) ? h >> 16 : h & 0xffffu) >= thresh;
+}
+// keep decisions of elements idx and idx + 1 for an EVEN idx: one hash
+__host__ __device__ static inline void vts_drop_keep2(unsigned long long seed, unsigned long long idx_even, unsigned thresh,
+                                                      bool& k0, bool& k1) {
+  const unsigned h = vts_hash32(seed, idx_even >> 1);
+  k0 = (h & 0xffffu) >= thresh;
+  k1 = (h >> 16) >= thresh;
+}
+// ... of idx .. idx + 3: two hashes when idx is even, the general route otherwise
+__host__ __device__ static inline void vts_drop_keep4(unsigned long long seed, unsigned long long idx, unsigned thresh,
+                                                      bool (&k)[4]) {
+  if ((idx & 1) == 0) {
+    vts_drop_keep2(seed, idx, thresh, k[0], k[1]);
+    vts_drop_keep2(seed, idx + 2, thresh, k[2], k[3]);
+  } else {
+    for (int e = 0; e < 4; ++e) k[e] = vts_drop_keep(seed, idx + e, thresh);
+  }
+}
 static inline unsigned vts_drop_thresh(float p) {
   if (!(p > 0.f)) return 0u;
-  const double t = (double)p * 4294967296.0;
-  return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  const double t = (double)p * 65536.0 + 0.5;
+  return t >= 65535.0 ? 65535u : (t < 1.0 ? 1u : (unsigned)t);
 }
 
 // How a dropout site gets its mask: explicit bytes (tests, replay of recorded draws), the counter
@@ -136,8 +160,22 @@ struct VtsDrop {
   float scale;                 // 1 / (1 - p)
   __device__ __forceinline__ float mult(unsigned long long idx) const {
     if (keep) return keep[idx] ? scale : 0.f;
-    if (thresh) return vts_hash32(seed, idx) >= thresh ? scale : 0.f;
+    if (thresh) return vts_drop_keep(seed, idx, thresh) ? scale : 0.f;
     return 1.f;
+  }
+  // the factors of elements idx and idx + 1, idx EVEN (one hash for the two)
+  __device__ __forceinline__ void mult2(unsigned long long idx_even, float& m0, float& m1) const {
+    if (keep) {
+      m0 = keep[idx_even] ? scale : 0.f;
+      m1 = keep[idx_even + 1] ? scale : 0.f;
+    } else if (thresh) {
+      bool k0, k1;
+      vts_drop_keep2(seed, idx_even, thresh, k0, k1);
+      m0 = k0 ? scale : 0.f;
+      m1 = k1 ? scale : 0.f;
+    } else {
+      m0 = m1 = 1.f;
+    }
   }
 };
 static inline VtsDrop vts_make_drop(const unsigned char* keep, float p, unsigned long long seed) {
