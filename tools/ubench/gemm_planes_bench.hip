@@ -36,12 +36,13 @@ struct Pol {
   int m0t, n0t;         // first row tile of this workgroup
   int s;                // k-step whose loads are being issued (advance() steps to the first one)
   SlabOut out;
+  int wrap;             // timing only: k-step s reads the tiles of k-step s % wrap (operands stay in the L2)
   __device__ __forceinline__ void advance() { ++s; }
   __device__ __forceinline__ const char* a_tile(int li) const {
-    return A + ((long)(s * 2 + (li & 1)) * mt_all + m0t + (li >> 1)) * gp::TILE_B;
+    return A + ((long)((s % wrap) * 2 + (li & 1)) * mt_all + m0t + (li >> 1)) * gp::TILE_B;
   }
   __device__ __forceinline__ const char* b_tile(int li) const {
-    return B + ((long)(s * 2 + (li & 1)) * nt_all + n0t + (li >> 1)) * gp::TILE_B;
+    return B + ((long)((s % wrap) * 2 + (li & 1)) * nt_all + n0t + (li >> 1)) * gp::TILE_B;
   }
   __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) { out.store(acc); }
 };
@@ -52,14 +53,15 @@ struct PolT {
   int acb0, bcb0;        // first column block of this workgroup
   int s;
   SlabOut out;
+  int wrap;
   __device__ __forceinline__ void advance() { ++s; }
   __device__ __forceinline__ const char* a_tile(int li) const {
     const int tt = li >> 4, cb = (li >> 1) & 7, p = li & 1;
-    return A + (((long)(2 * s + tt) * acb_all + acb0 + cb) * 2 + p) * gp::TILE_B;
+    return A + (((long)(2 * (s % wrap) + tt) * acb_all + acb0 + cb) * 2 + p) * gp::TILE_B;
   }
   __device__ __forceinline__ const char* b_tile(int li) const {
     const int tt = li >> 4, cb = (li >> 1) & 7, p = li & 1;
-    return B + (((long)(2 * s + tt) * bcb_all + bcb0 + cb) * 2 + p) * gp::TILE_B;
+    return B + (((long)(2 * (s % wrap) + tt) * bcb_all + bcb0 + cb) * 2 + p) * gp::TILE_B;
   }
   __device__ __forceinline__ void flush(f32x4 (&acc)[4][8]) { out.store(acc); }
 };
@@ -68,7 +70,7 @@ __device__ long long g_clk[2];     // shader-clock ticks (s_memtime) and 100 MHz
 
 template <int DBG, bool TRANS>
 __global__ __launch_bounds__(512) void wgrad_like_kernel(const char* A, const char* B, float* slabs, int M, int N,
-                                                            int ksteps, int ksplit) {
+                                                            int ksteps, int ksplit, int wrap) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const long long c0 = clock64(), w0 = wall_clock64();
   const int tiles_m = M / gp::TM, tiles_n = N / gp::TN, per = tiles_m * tiles_n;
@@ -79,10 +81,10 @@ __global__ __launch_bounds__(512) void wgrad_like_kernel(const char* A, const ch
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const SlabOut out{slabs + (long)z * M * N, N, tm, tn};
   if (TRANS) {
-    PolT pol{A, B, M / 32, N / 32, tm * 8, tn * 8, z * chunk - 1, out};
+    PolT pol{A, B, M / 32, N / 32, tm * 8, tn * 8, z * chunk - 1, out, wrap};
     gp::mainloop<PolT, true, 8, DBG>(pol, chunk, chunk, lds);
   } else {
-    Pol pol{A, B, M / 16, N / 16, tm * 16, tn * 16, z * chunk - 1, out};
+    Pol pol{A, B, M / 16, N / 16, tm * 16, tn * 16, z * chunk - 1, out, wrap};
     gp::mainloop<Pol, false, 8, DBG>(pol, chunk, chunk, lds);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -143,6 +145,9 @@ __global__ void fill_kernel(unsigned short* buf, int which, int rows, int ksteps
 int main(int argc, char** argv) {
   const int M = 1024, N = 512;
   const int big_steps = argc > 1 ? atoi(argv[1]) : 12288, ksplit_big = argc > 2 ? atoi(argv[2]) : 32;
+  // argv[4]: timing only - every k-step reads the operand tiles of k-step s % wrap, so that they come out of the L2
+  // (16 k-steps = 3 MiB of operands) instead of HBM: the same instruction stream without the memory system's share
+  const int wrap = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : 1 << 30;
 #define SETLDS(D, T) CK(hipFuncSetAttribute((const void*)wgrad_like_kernel<D, T>, hipFuncAttributeMaxDynamicSharedMemorySize, gp::LDS_B))
   SETLDS(0, false); SETLDS(1, false); SETLDS(2, false); SETLDS(0, true); SETLDS(1, true); SETLDS(2, true);
   char *A, *B; float* slabs;
@@ -157,8 +162,8 @@ int main(int argc, char** argv) {
     // ---- validation: 80 k-steps in 8 slices of 10, then 40 in 8 slices of 5 (even and odd step counts)
     for (int vs : {80, 40}) {
       const int ks = 8;
-      if (trans) hipLaunchKernelGGL((wgrad_like_kernel<0, true>), dim3(8 * 8), dim3(512), gp::LDS_B, 0, A, B, slabs, M, N, vs, ks);
-      else       hipLaunchKernelGGL((wgrad_like_kernel<0, false>), dim3(8 * 8), dim3(512), gp::LDS_B, 0, A, B, slabs, M, N, vs, ks);
+      if (trans) hipLaunchKernelGGL((wgrad_like_kernel<0, true>), dim3(8 * 8), dim3(512), gp::LDS_B, 0, A, B, slabs, M, N, vs, ks, 1 << 30);
+      else       hipLaunchKernelGGL((wgrad_like_kernel<0, false>), dim3(8 * 8), dim3(512), gp::LDS_B, 0, A, B, slabs, M, N, vs, ks, 1 << 30);
       CK(hipDeviceSynchronize());
       std::vector<float> h((size_t)ks * M * N);
       CK(hipMemcpy(h.data(), slabs, h.size() * 4, hipMemcpyDeviceToHost));
@@ -192,7 +197,7 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e0, 0));
       const int iters = 5;
       for (int i = 0; i < iters; ++i) {
-#define GO(D, T) hipLaunchKernelGGL((wgrad_like_kernel<D, T>), dim3(grid), dim3(512), gp::LDS_B, 0, A, B, slabs, M, N, big_steps, ksplit_big)
+#define GO(D, T) hipLaunchKernelGGL((wgrad_like_kernel<D, T>), dim3(grid), dim3(512), gp::LDS_B, 0, A, B, slabs, M, N, big_steps, ksplit_big, wrap)
         if (trans) { if (dbg == 0) GO(0, true); if (dbg == 1) GO(1, true); if (dbg == 2) GO(2, true); }
         else       { if (dbg == 0) GO(0, false); if (dbg == 1) GO(1, false); if (dbg == 2) GO(2, false); }
       }
@@ -201,6 +206,7 @@ int main(int argc, char** argv) {
       const double flop = 2.0 * M * N * 32.0 * big_steps;
       long long hc[2];
       CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), sizeof(hc)));
+      if (wrap < (1 << 30) && dbg == 0 && rep == 0) printf("operand k-steps wrap at %d\n", wrap);
       printf("trans %d dbg %d M %d N %d K %ld ksplit %d: %.3f ms, %.1f TFLOP/s algorithmic, %.1f executed = %.3f of 2500; shader clock %.2f GHz\n",
              trans, dbg, M, N, 32L * big_steps, ksplit_big, ms, flop / ms * 1e-9, 3 * flop / ms * 1e-9, 3 * flop / ms * 1e-9 / 2500.0,
              0.1 * (double)hc[0] / (double)hc[1]);
