@@ -211,7 +211,7 @@ static int linear_mode(int dtype_mode, int64_t M, int64_t N, int64_t K) {
 
 extern "C" {
 
-const char* vts_version(void) { return "vts-hip 0.6 (gfx950, fp32 + bf16x3 mfma, lstm + transformer encoders, plane GEMMs, cluster and pair recurrences, fused chains, recomputing feed-forward backward)"; }
+const char* vts_version(void) { return "vts-hip 0.7 (gfx950, fp32 + bf16x3 mfma, lstm + transformer encoders, plane GEMMs, cluster and pair recurrences, fused chains, recomputing feed-forward backward)"; }
 const char* vts_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------ LSTM
